@@ -1,0 +1,196 @@
+/*
+ * mipt.h -- C ABI of the MI355X path-tracing backend (libmipt.so).
+ *
+ * This is the drop-in boundary for the reference's renderer seam: the
+ * `match self.options.backend` in Renderer::render (reference src/renderer.rs:57-63)
+ * whose arms all have the shape (Renderer, &Scene) -> Vec<u8>
+ * (src/renderer/backend/cpu.rs:13, src/renderer/backend/gpu.rs:14).  A third arm
+ * `RendererBackend::MI355X` calls mipt_scene_create / mipt_render / mipt_scene_destroy
+ * (binding shown in INTEGRATION.md).  The payload is exactly what the reference's wgpu
+ * backend already ships to a device (src/renderer/backend/gpu.rs:329-339,356-367,455-459):
+ * bytemuck::Pod arrays of Triangle (112 B), Node (32 B), Material (80 B), RGBA8 textures
+ * and the 80-byte UniformCamera.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; every entry point returns
+ * 0 on success or a negative MiptStatus and never unwinds or aborts across the ABI; the
+ * message for the last failure on the calling thread is mipt_last_error().  Inputs are
+ * borrowed for the duration of the call only (mipt_scene_create copies to HBM); output
+ * buffers are caller-allocated.  The library fails loudly (MIPT_ERR_HIP) when no gfx950
+ * device or code object is available: there is no CPU fallback inside libmipt.so.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPT_ABI_VERSION 1
+
+/* ---- PODs, byte-identical to the reference's #[repr(C, align(16))] structs ---------- */
+typedef struct { float x, y, z; } MiptVec3;                 /* src/math/vec3.rs:55-59  (12 B) */
+
+typedef struct {                                            /* src/scene.rs:87-94      (32 B) */
+    MiptVec3 position; float tex_coord_x;
+    MiptVec3 normal;   float tex_coord_y;
+} MiptVertex;
+
+typedef struct {                                            /* src/scene.rs:97-103    (112 B) */
+    MiptVertex vertices[3];
+    uint32_t   material_id;
+    uint8_t    _pad[12];
+} MiptTriangle;
+
+typedef struct {                                            /* src/bvh.rs:164-171      (32 B) */
+    MiptVec3 bounds_min; uint32_t first_tri_or_child;
+    MiptVec3 bounds_max; uint32_t num_tris;                 /* leaf iff num_tris > 0 */
+} MiptNode;
+
+typedef struct {                                            /* src/scene.rs:129-146    (80 B) */
+    MiptVec3 base_color;    float transmission;
+    MiptVec3 specular_tint; float ior;
+    MiptVec3 emission;      float roughness;
+    float    metallic, transparency;
+    uint32_t base_color_tex_id, transparency_tex_id, roughness_tex_id,
+             metallic_tex_id, emission_tex_id, normal_tex_id;   /* UINT32_MAX = none */
+} MiptMaterial;
+
+typedef struct {                                            /* src/renderer/backend/gpu.rs:480-486 (80 B) */
+    float    look_at[4][4];                                 /* Mat4f data[col][row], src/math/mat4.rs:6-10 */
+    MiptVec3 position; float _pad;
+} MiptCamera;
+
+typedef struct {                                            /* src/texture.rs:4-10; payload as gpu.rs:360-367 */
+    uint32_t width, height;
+    const uint8_t *rgba8;                                   /* width*height*4 bytes, rows as stored by Texture::load (v-flipped) */
+} MiptTexture;
+
+typedef struct {                                            /* what StorageBuffers::new uploads, gpu.rs:329-391 */
+    const MiptTriangle *tris;      uint32_t n_tris;
+    const MiptNode     *nodes;     uint32_t n_nodes;        /* BVH::build output, src/bvh.rs:13-54 */
+    const MiptMaterial *materials; uint32_t n_materials;    /* indexed by Triangle.material_id */
+    const MiptTexture  *textures;  uint32_t n_textures;
+} MiptSceneDesc;
+
+typedef struct MiptScene MiptScene;                         /* opaque, device-resident */
+
+/* ---- options: RendererOptions (src/renderer.rs:96-104) + what the MI355X path adds ---- */
+enum MiptSeedMode {
+    MIPT_SEED_PIXEL_STREAM = 0,  /* cpu.rs:28-29: one xorshift stream per pixel, all samples in sequence */
+    MIPT_SEED_PER_SAMPLE   = 1   /* rt_compute.wgsl:102: reseed per (sample, x, y); splittable by sample */
+};
+enum MiptTraversal {
+    MIPT_TRAVERSAL_REFERENCE = 0, /* cpu/ray.rs:69-81: slab test without t-max cull (the CPU backend) */
+    MIPT_TRAVERSAL_CULLED    = 1  /* rt_compute.wgsl:341-349: + `t_near < best` cull (the wgpu backend) */
+};
+enum MiptFlags {
+    MIPT_FLAG_COUNT  = 1u << 0,   /* counting build: fill rays / inner_steps / tri_tests / ... in MiptStats */
+    MIPT_FLAG_PACKED = 1u << 1,   /* tile-sharded output is rank-packed (tile-major) instead of full-frame */
+    MIPT_FLAG_SUM    = 1u << 2    /* hdr = sum over samples (no division): sample-sharded accumulation */
+};
+
+typedef struct {
+    uint32_t width, height;       /* output_image_dimensions, renderer.rs:100 */
+    uint32_t samples;             /* renderer.rs:98  (> 0) */
+    uint32_t max_ray_depth;       /* renderer.rs:99  (> 0) */
+    uint32_t seed_mode;           /* MiptSeedMode */
+    uint32_t traversal;           /* MiptTraversal */
+    uint32_t flags;               /* MiptFlags */
+    uint32_t tile_rank;           /* image-tile shard: this rank ...                        */
+    uint32_t tile_world;          /* ... of this many (0 or 1 = whole image); 8x8 tiles, round-robin */
+    uint32_t sample_begin;        /* PER_SAMPLE: first sample number (0 -> 1, as gpu.rs:252 starts at 1) */
+    uint32_t reserved[6];         /* must be 0 */
+} MiptOptions;
+
+typedef struct {
+    double   kernel_ms;           /* HIP-event time of the trace kernel on its launch stream */
+    uint64_t rays;                /* traverse_bvh invocations (ray.rs:150) [COUNT] */
+    uint64_t inner_steps;         /* inner-node visits, two child records each [COUNT] */
+    uint64_t tri_tests;           /* intersect_tri calls [COUNT] */
+    uint64_t hits;                /* rays that hit [COUNT] */
+    uint64_t texel_fetches;       /* Texture::color_at calls [COUNT] */
+    uint64_t stack_overflows;     /* pushes dropped: traversal stack full (reference panics, ray.rs:85) */
+    uint64_t tex_clamped;         /* texel index clamped (reference panics, texture.rs:37) */
+    uint64_t max_stack;           /* deepest stack occupancy [COUNT] */
+    uint64_t pixels;              /* pixels this call produced */
+    uint64_t reserved[6];
+} MiptStats;
+
+enum MiptStatus {
+    MIPT_OK = 0,
+    MIPT_ERR_INVALID_ARG   = -1,  /* renderer.rs:15-26 invariants, null pointers, bad ranges */
+    MIPT_ERR_HIP           = -2,  /* HIP runtime error / no gfx950 device */
+    MIPT_ERR_SCENE_LIMIT   = -3,  /* scene exceeds device-format limits */
+    MIPT_ERR_BVH           = -4,  /* malformed BVH handed to mipt_scene_create */
+    MIPT_ERR_IO            = -5,  /* file not found / parse error (OBJ loader) */
+    MIPT_ERR_STACK         = -6   /* traversal stack overflowed during render (result incomplete) */
+};
+
+/* ---- the seam ----------------------------------------------------------------------- */
+
+/* Copies the scene to HBM of HIP device `device_id`, re-basing the BVH into 64-byte child-pair
+ * records and splitting triangles into a 48-byte intersection stream and a 64-byte shading
+ * stream.  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
+int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out);
+void mipt_scene_destroy(MiptScene *scene);
+
+/* Renders into HOST buffers and blocks until done.  Replaces cpu::render_scene
+ * (cpu.rs:13-68) / gpu::render_scene_to_buffer (gpu.rs:14-94).
+ *   hdr_rgb : width*height*3 f32, linear mean radiance per pixel (the value cpu.rs:60 holds
+ *             before sRGB), row 0 = top; may be NULL.
+ *   rgba8   : width*height*4 bytes, exactly the Vec<u8> cpu.rs:63-67 returns; may be NULL. */
+int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                float *hdr_rgb, uint8_t *rgba8, MiptStats *stats);
+
+/* Same, into DEVICE buffers (e.g. torch tensors), launched on `hip_stream` (hipStream_t, may
+ * be NULL = the null stream).  Blocks until the kernel has finished (stats are read back).
+ * With tile sharding and MIPT_FLAG_PACKED, d_hdr_rgb holds mipt_packed_pixels() * 3 floats. */
+int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                       float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats);
+
+/* Tile-shard helpers (image tiles shard across GPUs; one RCCL all-gather of packed slices). */
+uint64_t mipt_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_world);
+/* d_packed_all: tile_world slices of mipt_packed_pixels()*3 floats, rank-major (the layout an
+ * all-gather produces); writes the full width*height*3 frame. */
+int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height,
+                      uint32_t tile_world, float *d_hdr_rgb, void *hip_stream);
+/* linear HDR -> sRGB -> RGBA8 epilogue on device (vec3.rs:80-90, 262-270; cpu.rs:61-64).
+ * The radiance is first divided by `divisor` (the sample count for a summed buffer, cpu.rs:60;
+ * 1 for a buffer that already holds the mean). */
+int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor,
+                        uint8_t *d_rgba8, void *hip_stream);
+
+/* ---- host-side restatements of the scene model that feeds the path ------------------- */
+
+/* BVH::build (src/bvh.rs:13-161): binned SAH, 8 bins; reorders `tris` in place exactly as
+ * bvh.rs:99-108 does and emits the identical node array.  nodes_cap >= 2*n_tris-1.
+ * threads: 0 = hardware concurrency. */
+int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out,
+                   uint32_t nodes_cap, uint32_t *n_nodes_out, uint32_t threads);
+
+/* Scene::load for Wavefront OBJ + MTL (src/scene.rs:22-85, src/loader/obj.rs:16-436): parses the
+ * file, expands indexed faces into fat triangles and runs BVH::build.  The returned object owns
+ * host arrays; mipt_obj_get fills a MiptSceneDesc that borrows them (valid until mipt_obj_free)
+ * and, optionally, the material names in material-id order. */
+typedef struct MiptObj MiptObj;
+int  mipt_obj_load(const char *path, MiptObj **out);
+int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
+void mipt_obj_free(MiptObj *obj);
+
+/* Camera::update_view + Mat4f::look_at (src/scene.rs:181-194, src/math/mat4.rs:25-44). */
+int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg, MiptCamera *out);
+
+/* Material::default() (src/scene.rs:148-167). */
+void mipt_material_default(MiptMaterial *out);
+
+const char *mipt_last_error(void);
+int mipt_abi_version(void);
+/* number of HIP devices visible, or a negative MiptStatus */
+int mipt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of the CPU oracle (oracle/libpt_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+product package rust_ray_tracing_amd."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
+
+SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
+LIBM_SHIM, LIBM_HOST = 0, 1
+
+
+class OrcTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba8", C.c_void_p)]
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32), ("max_ray_depth", C.c_uint32),
+                ("seed_mode", C.c_uint32), ("cull", C.c_uint32), ("libm", C.c_uint32), ("threads", C.c_uint32),
+                ("pix_begin", C.c_uint64), ("pix_end", C.c_uint64), ("pix_stride", C.c_uint32),
+                ("sample_begin", C.c_uint32), ("stack_cap", C.c_uint32), ("sum_only", C.c_uint32)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("inner_steps", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
+                ("texel_fetches", C.c_uint64), ("stack_overflows", C.c_uint64), ("max_stack", C.c_uint64),
+                ("tex_clamped", C.c_uint64), ("seconds", C.c_double), ("threads_used", C.c_uint32), ("_pad", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "_pad"}
+
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libpt_oracle.so"])
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
+    lib.orc_bvh_build.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
+    lib.orc_bvh_build.restype = C.c_int
+    lib.orc_camera_from_pose.argtypes = [C.POINTER(f32 * 3), f32, f32, vp]
+    lib.orc_camera_from_pose.restype = None
+    lib.orc_render.argtypes = [vp, u32, vp, u32, vp, u32, C.POINTER(OrcTexture), u32, vp, C.POINTER(OrcOptions), vp, vp, C.POINTER(OrcStats)]
+    lib.orc_render.restype = C.c_int
+    lib.orc_pixel_seed.argtypes = [u32]
+    lib.orc_pixel_seed.restype = u32
+    lib.orc_sample_seed.argtypes = [u32, u32, u32]
+    lib.orc_sample_seed.restype = u32
+    lib.orc_xor_shift.argtypes = [C.POINTER(u32)]
+    lib.orc_xor_shift.restype = u32
+    lib.orc_rand_f32.argtypes = [C.POINTER(u32)]
+    lib.orc_rand_f32.restype = f32
+    lib.orc_rand_f32_nd.argtypes = [C.POINTER(u32), C.c_int]
+    lib.orc_rand_f32_nd.restype = f32
+    lib.orc_rand_in_unit_sphere.argtypes = [C.POINTER(u32), C.c_int, C.POINTER(f32 * 3)]
+    lib.orc_rand_in_unit_sphere.restype = None
+    lib.orc_intersect_node.argtypes = [C.POINTER(f32 * 3), C.POINTER(f32 * 3), vp]
+    lib.orc_intersect_node.restype = f32
+    lib.orc_intersect_tri.argtypes = [C.POINTER(f32 * 3), C.POINTER(f32 * 3), vp, C.POINTER(f32 * 13)]
+    lib.orc_intersect_tri.restype = None
+    lib.orc_linear_to_srgb.argtypes = [C.POINTER(f32 * 3), C.c_int, C.POINTER(f32 * 3)]
+    lib.orc_linear_to_srgb.restype = None
+    lib.orc_quantize.argtypes = [C.POINTER(f32 * 3), C.POINTER(C.c_uint8 * 3)]
+    lib.orc_quantize.restype = None
+    lib.orc_texture_color_at.argtypes = [C.POINTER(OrcTexture), f32, f32, C.POINTER(C.c_uint8 * 4)]
+    lib.orc_texture_color_at.restype = None
+    lib.orc_pixel_screen.argtypes = [u32, u32, u32, C.POINTER(f32 * 2)]
+    lib.orc_pixel_screen.restype = None
+    for name in ("orc_shim_cosf", "orc_shim_log10f"):
+        getattr(lib, name).argtypes = [f32]
+        getattr(lib, name).restype = f32
+    lib.orc_shim_powf.argtypes = [f32, f32]
+    lib.orc_shim_powf.restype = f32
+    lib.orc_trace_ray.argtypes = [vp, u32, vp, u32, vp, u32, C.POINTER(OrcTexture), u32, C.POINTER(f32 * 3), C.POINTER(f32 * 3),
+                                  u32, C.POINTER(u32), C.c_int, C.c_int, C.POINTER(f32 * 3)]
+    lib.orc_trace_ray.restype = None
+    _lib = lib
+    return lib
+
+
+def _tex_array(textures):
+    arr = (OrcTexture * max(len(textures), 1))()
+    for i, t in enumerate(textures):
+        arr[i].width, arr[i].height, arr[i].rgba8 = t.shape[1], t.shape[0], t.ctypes.data
+    return arr
+
+
+def bvh_build(tris: np.ndarray):
+    """orc_bvh_build on a COPY of tris -> (reordered tris, nodes)."""
+    from_dtype = tris.dtype
+    t = np.ascontiguousarray(tris).copy()
+    nodes = np.zeros((max(2 * len(t), 1), 32), dtype=np.uint8)
+    n = C.c_uint32(0)
+    rc = load().orc_bvh_build(t.ctypes.data, len(t), nodes.ctypes.data, len(nodes), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"orc_bvh_build failed: {rc}")
+    return t.view(from_dtype), nodes[: n.value].copy()
+
+
+def camera_from_pose(position, pitch, yaw) -> np.ndarray:
+    out = np.zeros(80, dtype=np.uint8)
+    pos = (C.c_float * 3)(*[float(x) for x in position])
+    load().orc_camera_from_pose(C.byref(pos), pitch, yaw, out.ctypes.data)
+    return out
+
+
+def render(tris, nodes, materials, textures, camera, width, height, samples, max_ray_depth, *, seed_mode=0, cull=0,
+           libm=LIBM_SHIM, threads=0, pix_begin=0, pix_end=0, pix_stride=0, sample_begin=0, sum_only=0, stack_cap=0,
+           want_rgba8=True):
+    """Returns (hdr [h,w,3] f32, rgba8 [h,w,4] u8 | None, stats dict).  Arrays may be any dtype of the right byte size."""
+    tris = np.ascontiguousarray(tris)
+    nodes = np.ascontiguousarray(nodes)
+    materials = np.ascontiguousarray(materials)
+    camera = np.ascontiguousarray(camera)
+    textures = [np.ascontiguousarray(t) for t in textures]
+    opt = OrcOptions(width, height, samples, max_ray_depth, seed_mode, cull, libm, threads, pix_begin, pix_end, pix_stride,
+                     sample_begin, stack_cap, sum_only)
+    hdr = np.zeros((height, width, 3), dtype=np.float32)
+    rgba = np.zeros((height, width, 4), dtype=np.uint8) if want_rgba8 else None
+    st = OrcStats()
+    n_tris = tris.nbytes // 112
+    n_nodes = nodes.nbytes // 32
+    n_mats = materials.nbytes // 80
+    rc = load().orc_render(tris.ctypes.data, n_tris, nodes.ctypes.data, n_nodes, materials.ctypes.data, n_mats,
+                           _tex_array(textures), len(textures), camera.ctypes.data, C.byref(opt), hdr.ctypes.data,
+                           rgba.ctypes.data if want_rgba8 else None, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    return hdr, rgba, st.as_dict()

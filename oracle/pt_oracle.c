@@ -1,0 +1,691 @@
+/*
+ * pt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See pt_oracle.h for scope, provenance and the "parity unpinned" statement.
+ *
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math).  Rust never
+ * contracts a*b+c into an FMA and rounds every f32 operation separately
+ * (SURVEY.md T11); this file is written the same way: one rounded IEEE-754
+ * binary32 operation per source-level operator, evaluated in the reference's
+ * order.
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+/* FMA contraction is disabled by -ffp-contract=off in oracle/Makefile (gcc ignores the STDC pragma) */
+
+_Static_assert(sizeof(OrcVec3) == 12, "Vec3f");
+_Static_assert(sizeof(OrcVertex) == 32, "Vertex");
+_Static_assert(sizeof(OrcTriangle) == 112, "Triangle");
+_Static_assert(__builtin_offsetof(OrcTriangle, material_id) == 96, "Triangle.material_id");
+_Static_assert(sizeof(OrcNode) == 32, "Node");
+_Static_assert(__builtin_offsetof(OrcNode, first_tri_or_child) == 12, "Node.first");
+_Static_assert(__builtin_offsetof(OrcNode, bounds_max) == 16, "Node.max");
+_Static_assert(__builtin_offsetof(OrcNode, num_tris) == 28, "Node.num");
+_Static_assert(sizeof(OrcMaterial) == 80, "Material");
+_Static_assert(__builtin_offsetof(OrcMaterial, ior) == 28, "Material.ior");
+_Static_assert(__builtin_offsetof(OrcMaterial, emission) == 32, "Material.emission");
+_Static_assert(__builtin_offsetof(OrcMaterial, base_color_tex_id) == 56, "Material.tex");
+_Static_assert(sizeof(OrcCamera) == 80, "UniformCamera");
+_Static_assert(__builtin_offsetof(OrcCamera, position) == 64, "UniformCamera.position");
+
+#define ORC_MISS 1e30f                         /* ray.rs:79, :217 */
+#define ORC_F32_MAX 3.40282346638528859812e+38f
+
+/* ------------------------------------------------------------------------- */
+/* Deterministic transcendental shim.                                         */
+/* The reference calls Rust std f32::{cos,log10,powf} = the platform libm     */
+/* (math.rs:16-18, vec3.rs:87).  libm's last-ulp results are not reproducible */
+/* on a GPU, so oracle and kernel both evaluate the functions below: IEEE     */
+/* binary64 + - * / only, fixed order, no FMA, result rounded once to f32.    */
+/* The kernel carries its own copy of this spec (csrc/mipt_device_math.h).    */
+/* ------------------------------------------------------------------------- */
+static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+static double shim_ksin(double r) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = r * r;
+    double p = S6;
+    p = S5 + z * p; p = S4 + z * p; p = S3 + z * p; p = S2 + z * p; p = S1 + z * p;
+    return r + (r * z) * p;
+}
+static double shim_kcos(double r) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = r * r;
+    double p = C6;
+    p = C5 + z * p; p = C4 + z * p; p = C3 + z * p; p = C2 + z * p; p = C1 + z * p;
+    return (1.0 - 0.5 * z) + (z * z) * p;
+}
+float orc_shim_cosf(float x) {
+    if (!(fabsf(x) <= 1048576.0f)) {             /* NaN, inf, or out of the shim's range */
+        return x - x;                            /* NaN for inf/NaN; callers stay within range */
+    }
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;   /* first 33 bits of pi/2 */
+    const double PIO2_1T = 6.07710050650619224932e-11;  /* pi/2 - PIO2_1 */
+    double xd = (double)x;
+    double kf = floor(xd * INV_PIO2 + 0.5);
+    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
+    long long k = (long long)kf;
+    double c;
+    switch (k & 3) {
+    case 0: c = shim_kcos(r); break;
+    case 1: c = -shim_ksin(r); break;
+    case 2: c = -shim_kcos(r); break;
+    default: c = shim_ksin(r); break;
+    }
+    return (float)c;
+}
+
+/* ln(m) for xd = m * 2^e, m in [sqrt(1/2), sqrt(2)); xd positive, finite, normal */
+static double shim_log_reduce(double xd, double *e_out) {
+    const double SQRT2 = 1.41421356237309514547e+00;
+    uint64_t b = d2u(xd);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    double m = u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > SQRT2) { m = m * 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 4.34782608695652161754e-02;            /* 1/23 */
+    p = 4.76190476190476164085e-02 + z * p;           /* 1/21 */
+    p = 5.26315789473684181249e-02 + z * p;           /* 1/19 */
+    p = 5.88235294117647050660e-02 + z * p;           /* 1/17 */
+    p = 6.66666666666666657415e-02 + z * p;           /* 1/15 */
+    p = 7.69230769230769273453e-02 + z * p;           /* 1/13 */
+    p = 9.09090909090909116141e-02 + z * p;           /* 1/11 */
+    p = 1.11111111111111104943e-01 + z * p;           /* 1/9  */
+    p = 1.42857142857142849213e-01 + z * p;           /* 1/7  */
+    p = 2.00000000000000011102e-01 + z * p;           /* 1/5  */
+    p = 3.33333333333333314830e-01 + z * p;           /* 1/3  */
+    p = 1.0 + z * p;
+    *e_out = (double)e;
+    return (2.0 * s) * p;
+}
+float orc_shim_log10f(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return (x - x) / (x - x);            /* NaN */
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    const double LOG10_2 = 3.01029995663981198017e-01;
+    const double INV_LN10 = 4.34294481903251816668e-01;
+    double e, lm = shim_log_reduce((double)x, &e);
+    return (float)(e * LOG10_2 + lm * INV_LN10);
+}
+static double shim_exp(double z) {                    /* z in [-110, 100] */
+    const double INV_LN2 = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double kf = floor(z * INV_LN2 + 0.5);
+    double r = (z - kf * LN2_HI) - kf * LN2_LO;
+    double p = 1.60590438368216133e-10;               /* 1/13! */
+    p = 2.08767569878680989792e-09 + r * p;           /* 1/12! */
+    p = 2.50521083854417187751e-08 + r * p;           /* 1/11! */
+    p = 2.75573192239858906526e-07 + r * p;           /* 1/10! */
+    p = 2.75573192239858906526e-06 + r * p;           /* 1/9!  */
+    p = 2.48015873015873015873e-05 + r * p;           /* 1/8!  */
+    p = 1.98412698412698412698e-04 + r * p;           /* 1/7!  */
+    p = 1.38888888888888894189e-03 + r * p;           /* 1/6!  */
+    p = 8.33333333333333321769e-03 + r * p;           /* 1/5!  */
+    p = 4.16666666666666643537e-02 + r * p;           /* 1/4!  */
+    p = 1.66666666666666657415e-01 + r * p;           /* 1/3!  */
+    p = 0.5 + r * p;
+    p = 1.0 + r * p;
+    p = 1.0 + r * p;
+    long long k = (long long)kf;
+    double scale = u2d((uint64_t)(k + 1023) << 52);
+    return p * scale;
+}
+float orc_shim_powf(float x, float y) {
+    if (y == 0.0f || x == 1.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    if (x < 0.0f) return (x - x) / (x - x);           /* NaN: the path never raises a negative to an integer */
+    if (x == 0.0f) return y > 0.0f ? 0.0f : INFINITY;
+    if (x == INFINITY) return y > 0.0f ? INFINITY : 0.0f;
+    if (y == INFINITY) return x > 1.0f ? INFINITY : 0.0f;
+    if (y == -INFINITY) return x > 1.0f ? 0.0f : INFINITY;
+    const double LN2 = 6.93147180559945286227e-01;
+    double e, lm = shim_log_reduce((double)x, &e);
+    double z = (double)y * (e * LN2 + lm);
+    if (z > 100.0) return INFINITY;
+    if (z < -110.0) return 0.0f;
+    return (float)shim_exp(z);
+}
+
+static inline float f_cos(float x, int libm)   { return libm == ORC_LIBM_HOST ? cosf(x) : orc_shim_cosf(x); }
+static inline float f_log10(float x, int libm) { return libm == ORC_LIBM_HOST ? log10f(x) : orc_shim_log10f(x); }
+static inline float f_pow(float x, float y, int libm) { return libm == ORC_LIBM_HOST ? powf(x, y) : orc_shim_powf(x, y); }
+
+/* ------------------------------------------------------------------------- */
+/* math.rs / vec3.rs / vec2.rs / mat4.rs subset                               */
+/* ------------------------------------------------------------------------- */
+typedef OrcVec3 v3;
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }      /* vec3.rs:272-278 */
+static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }      /* vec3.rs:288-294 */
+static inline v3 v_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }      /* vec3.rs:304-310 */
+static inline v3 v_muls(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }        /* vec3.rs:312-318 */
+static inline v3 v_div(v3 a, v3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }      /* vec3.rs:336-342 */
+static inline v3 v_divs(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }        /* vec3.rs:344-350 */
+static inline float v_dot(v3 a, v3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); } /* vec3.rs:130-134 */
+static inline v3 v_cross(v3 a, v3 b) {                                                  /* vec3.rs:136-144 */
+    return V3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+static inline float v_length(v3 a) { return sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); } /* vec3.rs:93-97 */
+static inline v3 v_normalized(v3 a) { return v_divs(a, v_length(a)); }                  /* vec3.rs:105-109 */
+/* f32::min / f32::max are IEEE minNum / maxNum (NaN-ignoring) = C fminf / fmaxf (T5) */
+static inline v3 v_min(v3 a, v3 b) { return V3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); } /* vec3.rs:146-154 */
+static inline v3 v_max(v3 a, v3 b) { return V3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); } /* vec3.rs:155-163 */
+
+uint32_t orc_xor_shift(uint32_t *state) {              /* math.rs:6-13 */
+    uint32_t x = *state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    *state = x;
+    return x;
+}
+float orc_rand_f32(uint32_t *state) {                  /* math.rs:22-24; u32::MAX as f32 == 2^32 (T1) */
+    return (float)orc_xor_shift(state) / 4294967296.0f;
+}
+float orc_rand_f32_nd(uint32_t *state, int libm) {     /* math.rs:15-19 (log10, not ln: T3) */
+    float theta = 6.283185f * orc_rand_f32(state);
+    float rho = sqrtf(-2.0f * f_log10(orc_rand_f32(state), libm));
+    return rho * f_cos(theta, libm);
+}
+void orc_rand_in_unit_sphere(uint32_t *state, int libm, float out[3]) { /* vec3.rs:66-68 */
+    float x = orc_rand_f32_nd(state, libm);
+    float y = orc_rand_f32_nd(state, libm);
+    float z = orc_rand_f32_nd(state, libm);
+    v3 n = v_normalized(V3(x, y, z));
+    out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+uint32_t orc_pixel_seed(uint32_t index) {              /* cpu.rs:28-29 */
+    return 987612486u * (index + 87636354u);
+}
+uint32_t orc_sample_seed(uint32_t s, uint32_t x, uint32_t y) { /* rt_compute.wgsl:102 */
+    return s * 6023u + (757283u * x + 872653746u * y);
+}
+static inline v3 mat_mul_v3(const float m[4][4], v3 r) { /* mat4.rs:143-152 (upper-left 3x3, data[col][row]) */
+    float x = m[0][0] * r.x + m[1][0] * r.y + m[2][0] * r.z;
+    float y = m[0][1] * r.x + m[1][1] * r.y + m[2][1] * r.z;
+    float z = m[0][2] * r.x + m[1][2] * r.y + m[2][2] * r.z;
+    return V3(x, y, z);
+}
+
+void orc_linear_to_srgb(const float in[3], int libm, float out[3]) { /* vec3.rs:80-90, mix :197-205 */
+    for (int i = 0; i < 3; i++) {
+        float c = in[i];
+        float cutoff = (c < 0.0031308f) ? 1.0f : 0.0f;
+        float higher = 1.055f * f_pow(c, 1.0f / 2.4f, libm) - 0.055f;
+        float lower = c * 12.92f;
+        out[i] = (higher * (1.0f - cutoff)) + lower * cutoff;
+    }
+}
+void orc_quantize(const float in[3], uint8_t out[3]) { /* vec3.rs:262-270; NaN -> 0 (Rust `as u8`) */
+    for (int i = 0; i < 3; i++) {
+        float c = floorf(in[i] * 255.0f);
+        if (c < 0.0f) c = 0.0f;                 /* f32::clamp keeps NaN; `as u8` then maps it to 0 */
+        if (c > 255.0f) c = 255.0f;
+        out[i] = (c != c) ? 0 : (uint8_t)c;
+    }
+}
+static inline int32_t f32_as_i32(float f) {           /* Rust `as i32`: saturating, NaN -> 0 */
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+static int tex_lookup(const OrcTexture *t, float u, float v, uint8_t out[4]) { /* texture.rs:33-38 */
+    float fu = u - truncf(u), fv = v - truncf(v);      /* f32::fract */
+    int32_t i = f32_as_i32(fu * (float)t->width);
+    int32_t j = f32_as_i32(fv * (float)t->height);
+    int64_t index = (int64_t)i + (int64_t)j * (int64_t)t->width;
+    int64_t n = (int64_t)t->width * (int64_t)t->height;
+    int clamped = 0;
+    if (index < 0) { index = 0; clamped = 1; }         /* the reference would panic here (T10) */
+    if (index >= n) { index = n - 1; clamped = 1; }
+    memcpy(out, t->rgba8 + 4 * index, 4);
+    return clamped;
+}
+void orc_texture_color_at(const OrcTexture *t, float u, float v, uint8_t out[4]) { tex_lookup(t, u, v, out); }
+
+void orc_pixel_screen(uint32_t index, uint32_t w, uint32_t h, float out[2]) { /* cpu.rs:31-35 (T9) */
+    uint32_t x = index % w;
+    uint32_t y = h - (index / w);
+    out[0] = ((((float)x / (float)w) * 2.0f) - 1.0f) * ((float)w / (float)h);
+    out[1] = (((float)y / (float)h) * 2.0f) - 1.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* cpu/ray.rs                                                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct { v3 origin, direction; } Ray;
+typedef struct {                                      /* ray.rs:205-227 */
+    int has_hit; v3 point, normal; float distance; float uvx, uvy;
+    uint32_t material_id; int front_face; float u, v;
+} Hit;
+
+typedef struct {
+    const OrcTriangle *tris; uint32_t n_tris;
+    const OrcNode *nodes; uint32_t n_nodes;
+    const OrcMaterial *materials; uint32_t n_materials;
+    const OrcTexture *textures; uint32_t n_textures;
+} SceneView;
+
+static Hit intersect_tri(const Ray *ray, const OrcTriangle *tri) { /* ray.rs:19-67 */
+    v3 v_1 = tri->vertices[0].position, v_2 = tri->vertices[1].position, v_3 = tri->vertices[2].position;
+    v3 edge_1 = v_sub(v_2, v_1);
+    v3 edge_2 = v_sub(v_3, v_1);
+    v3 ray_cross_e2 = v_cross(ray->direction, edge_2);
+    float det = v_dot(edge_1, ray_cross_e2);
+    float inv_det = 1.0f / det;
+    v3 s = v_sub(ray->origin, v_1);
+    float u = inv_det * v_dot(s, ray_cross_e2);
+    v3 s_cross_e1 = v_cross(s, edge_1);
+    float v = inv_det * v_dot(ray->direction, s_cross_e1);
+    float t = inv_det * v_dot(edge_2, s_cross_e1);
+    int front_face = det > 0.0f;
+    float w = 1.0f - u - v;
+    v3 normal = v_add(v_add(v_muls(tri->vertices[0].normal, w), v_muls(tri->vertices[1].normal, u)),
+                      v_muls(tri->vertices[2].normal, v));
+    if (!front_face) normal = V3(-normal.x, -normal.y, -normal.z);
+    Hit h;
+    h.uvx = ((tri->vertices[0].tex_coord_x * w) + (tri->vertices[1].tex_coord_x * u)) + (tri->vertices[2].tex_coord_x * v);
+    h.uvy = ((tri->vertices[0].tex_coord_y * w) + (tri->vertices[1].tex_coord_y * u)) + (tri->vertices[2].tex_coord_y * v);
+    /* exact boolean form of ray.rs:56-59 -- NaN u/v pass, NaN t fails (T4) */
+    h.has_hit = (t > 0.0f) && !(det < 0.0f && det > -0.0f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
+    h.point = v_add(ray->origin, v_muls(ray->direction, t));
+    h.normal = normal;
+    h.distance = t;
+    h.material_id = tri->material_id;
+    h.front_face = front_face;
+    h.u = u; h.v = v;
+    return h;
+}
+
+static inline float intersect_node(const Ray *ray, const OrcNode *node, int cull, float max_distance) {
+    /* ray.rs:69-81; cull=1 adds rt_compute.wgsl:348's `t_near < max_distance` */
+    v3 t_min = v_div(v_sub(node->bounds_min, ray->origin), ray->direction);
+    v3 t_max = v_div(v_sub(node->bounds_max, ray->origin), ray->direction);
+    v3 t_1 = v_min(t_min, t_max);
+    v3 t_2 = v_max(t_min, t_max);
+    float t_near = fmaxf(fmaxf(t_1.x, t_1.y), t_1.z);
+    float t_far = fminf(fminf(t_2.x, t_2.y), t_2.z);
+    if (t_near <= t_far && t_far > 0.0f && (!cull || t_near < max_distance)) return t_near;
+    return ORC_MISS;
+}
+
+typedef struct { OrcStats s; uint32_t stack_cap; int cull; int libm; } Ctx;
+
+#define ORC_STACK_MAX 256
+static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx) { /* ray.rs:84-139 */
+    uint32_t stack[ORC_STACK_MAX];                   /* node indices; the reference stacks Node copies */
+    uint32_t sp = 0;
+    const OrcNode *node = &sc->nodes[0];
+    cx->s.rays++;
+    for (;;) {
+        if (node->num_tris > 0) {
+            for (uint32_t i = 0; i < node->num_tris; i++) {
+                Hit th = intersect_tri(ray, &sc->tris[node->first_tri_or_child + i]);
+                cx->s.tri_tests++;
+                if (th.has_hit && th.distance < hit->distance) *hit = th;
+            }
+            if (sp == 0) break;
+            node = &sc->nodes[stack[--sp]];
+            continue;
+        }
+        uint32_t c1 = node->first_tri_or_child, c2 = c1 + 1;
+        cx->s.inner_steps++;
+        float dist_1 = intersect_node(ray, &sc->nodes[c1], cx->cull, hit->distance);
+        float dist_2 = intersect_node(ray, &sc->nodes[c2], cx->cull, hit->distance);
+        if (dist_1 > dist_2) {
+            float td = dist_1; dist_1 = dist_2; dist_2 = td;
+            uint32_t tc = c1; c1 = c2; c2 = tc;
+        }
+        if (dist_1 == ORC_MISS) {
+            if (sp == 0) break;
+            node = &sc->nodes[stack[--sp]];
+        } else {
+            node = &sc->nodes[c1];
+            if (dist_2 < ORC_MISS) {
+                if (sp < cx->stack_cap) {
+                    stack[sp++] = c2;
+                    if (sp > cx->s.max_stack) cx->s.max_stack = sp;
+                } else {
+                    cx->s.stack_overflows++;         /* the reference panics here (ray.rs:85,134) */
+                }
+            }
+        }
+    }
+}
+
+static v3 trace(Ray *ray, uint32_t max_bounces, const SceneView *sc, uint32_t *rng, Ctx *cx) { /* ray.rs:141-202 */
+    v3 ray_color = V3(1.0f, 1.0f, 1.0f);
+    v3 incoming_light = V3(0.0f, 0.0f, 0.0f);
+    v3 emitted_light = V3(0.0f, 0.0f, 0.0f);
+    uint32_t curr_bounces = 0;
+    while (curr_bounces < max_bounces) {
+        Hit hit;
+        memset(&hit, 0, sizeof hit);
+        hit.distance = ORC_MISS;
+        traverse_bvh(ray, sc, &hit, cx);
+        if (hit.has_hit) {
+            cx->s.hits++;
+            const OrcMaterial *m = &sc->materials[hit.material_id];   /* ray.rs:153-154 */
+            /* ray.rs:155-160: `ior` is computed and never used on the CPU path (T8) */
+            if (m->base_color_tex_id != UINT32_MAX) {                  /* ray.rs:162-169 */
+                uint8_t px[4];
+                cx->s.tex_clamped += tex_lookup(&sc->textures[m->base_color_tex_id], hit.uvx, hit.uvy, px);
+                cx->s.texel_fetches++;
+                ray_color = v_mul(ray_color, V3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f));
+            } else {
+                ray_color = v_mul(ray_color, m->base_color);
+            }
+            if (m->emission_tex_id != UINT32_MAX) {                    /* ray.rs:170-176 */
+                uint8_t px[4];
+                cx->s.tex_clamped += tex_lookup(&sc->textures[m->emission_tex_id], hit.uvx, hit.uvy, px);
+                cx->s.texel_fetches++;
+                emitted_light = v_add(emitted_light, V3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f));
+            } else {
+                emitted_light = v_add(emitted_light, m->emission);
+            }
+            incoming_light = v_add(incoming_light, v_mul(emitted_light, ray_color)); /* ray.rs:177 */
+            float rs[3];
+            orc_rand_in_unit_sphere(rng, cx->libm, rs);
+            v3 new_dir = v_normalized(v_add(hit.normal, V3(rs[0], rs[1], rs[2])));   /* ray.rs:179-180 (T7) */
+            ray->origin = v_add(hit.point, v_muls(new_dir, 0.0001f));                 /* ray.rs:181 */
+            ray->direction = new_dir;
+            curr_bounces += 1;
+        } else {
+            ray_color = v_mul(ray_color, V3(1.0f, 1.0f, 1.0f));       /* ray.rs:184-193 */
+            emitted_light = v_add(emitted_light, V3(1.0f, 1.0f, 1.0f));
+            incoming_light = v_add(incoming_light, v_mul(emitted_light, ray_color));
+            break;
+        }
+    }
+    if (curr_bounces == 0) return incoming_light;                      /* ray.rs:197-201 */
+    return v_divs(incoming_light, (float)curr_bounces);
+}
+
+float orc_intersect_node(const float o[3], const float d[3], const OrcNode *n) {
+    Ray r = {V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2])};
+    return intersect_node(&r, n, 0, ORC_MISS);
+}
+void orc_intersect_tri(const float o[3], const float d[3], const OrcTriangle *t, float out[13]) {
+    Ray r = {V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2])};
+    Hit h = intersect_tri(&r, t);
+    out[0] = (float)h.has_hit; out[1] = h.distance; out[2] = h.u; out[3] = h.v; out[4] = (float)h.front_face;
+    out[5] = h.normal.x; out[6] = h.normal.y; out[7] = h.normal.z; out[8] = h.uvx; out[9] = h.uvy;
+    out[10] = h.point.x; out[11] = h.point.y; out[12] = h.point.z;
+}
+void orc_trace_ray(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+                   const OrcMaterial *materials, uint32_t n_materials,
+                   const OrcTexture *textures, uint32_t n_textures,
+                   const float o[3], const float d[3], uint32_t max_depth,
+                   uint32_t *rng, int cull, int libm, float out[3]) {
+    SceneView sc = {tris, n_tris, nodes, n_nodes, materials, n_materials, textures, n_textures};
+    Ctx cx; memset(&cx, 0, sizeof cx);
+    cx.stack_cap = 64; cx.cull = cull; cx.libm = libm;
+    Ray r = {V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2])};
+    v3 c = trace(&r, max_depth, &sc, rng, &cx);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+/* ------------------------------------------------------------------------- */
+/* cpu.rs:13-68 -- the pixel loop                                             */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    SceneView sc; const OrcCamera *cam; OrcOptions opt;
+    float *hdr; uint8_t *rgba8;
+    uint64_t n_items, block; volatile uint64_t next_block;
+    pthread_mutex_t mu; OrcStats total;
+} Job;
+
+static void render_pixel(Job *job, uint64_t index, Ctx *cx) {
+    const OrcOptions *o = &job->opt;
+    uint32_t w = o->width, h = o->height;
+    uint32_t rng = orc_pixel_seed((uint32_t)index);                    /* cpu.rs:28-29 */
+    v3 final_color = V3(0.0f, 0.0f, 0.0f);
+    uint32_t x = (uint32_t)(index % w);
+    uint32_t y = h - (uint32_t)(index / w);                            /* cpu.rs:31-32 (T9) */
+    float screen_x = ((((float)x / (float)w) * 2.0f) - 1.0f) * ((float)w / (float)h);
+    float screen_y = (((float)y / (float)h) * 2.0f) - 1.0f;
+    uint32_t s0 = o->sample_begin ? o->sample_begin : 1u;
+    for (uint32_t s = 0; s < o->samples; s++) {                        /* cpu.rs:37 */
+        if (o->seed_mode == ORC_SEED_PER_SAMPLE)
+            rng = orc_sample_seed(s0 + s, x, (uint32_t)(index / w));   /* rt_compute.wgsl:102, global_id.y = row */
+        float jx = (orc_rand_f32(&rng) * 2.0f - 1.0f) * 0.0005f;       /* cpu.rs:38-42 */
+        float jy = (orc_rand_f32(&rng) * 2.0f - 1.0f) * 0.0005f;
+        v3 dir = v_normalized(mat_mul_v3(job->cam->look_at, V3(-screen_x + jx, screen_y + jy, 1.0f))); /* cpu.rs:43-45 */
+        Ray ray = {job->cam->position, dir};                           /* cpu.rs:46-50 */
+        final_color = v_add(final_color, trace(&ray, o->max_ray_depth, &job->sc, &rng, cx)); /* cpu.rs:52-57 */
+    }
+    if (!o->sum_only) final_color = v_divs(final_color, (float)o->samples); /* cpu.rs:60 */
+    if (job->hdr) {
+        job->hdr[3 * index + 0] = final_color.x;
+        job->hdr[3 * index + 1] = final_color.y;
+        job->hdr[3 * index + 2] = final_color.z;
+    }
+    if (job->rgba8) {
+        float lin[3] = {final_color.x, final_color.y, final_color.z}, srgb[3];
+        uint8_t q[3];
+        orc_linear_to_srgb(lin, cx->libm, srgb);                       /* cpu.rs:61 */
+        orc_quantize(srgb, q);                                         /* cpu.rs:63 */
+        uint8_t *p = job->rgba8 + 4 * index;
+        p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = 255;             /* cpu.rs:64 */
+    }
+}
+
+static void *worker(void *arg) {
+    Job *job = (Job *)arg;
+    Ctx cx; memset(&cx, 0, sizeof cx);
+    cx.stack_cap = job->opt.stack_cap ? job->opt.stack_cap : 64;
+    if (cx.stack_cap > ORC_STACK_MAX) cx.stack_cap = ORC_STACK_MAX;
+    cx.cull = (int)job->opt.cull; cx.libm = (int)job->opt.libm;
+    uint64_t stride = job->opt.pix_stride ? job->opt.pix_stride : 1;
+    for (;;) {
+        /* rayon's by_uniform_blocks (cpu.rs:22-26): contiguous blocks of w*h/T pixel indices */
+        uint64_t b = __atomic_fetch_add(&job->next_block, 1, __ATOMIC_RELAXED);
+        uint64_t lo = b * job->block;
+        if (lo >= job->n_items) break;
+        uint64_t hi = lo + job->block; if (hi > job->n_items) hi = job->n_items;
+        for (uint64_t i = lo; i < hi; i++) render_pixel(job, job->opt.pix_begin + i * stride, &cx);
+    }
+    pthread_mutex_lock(&job->mu);
+    job->total.rays += cx.s.rays; job->total.inner_steps += cx.s.inner_steps;
+    job->total.tri_tests += cx.s.tri_tests; job->total.hits += cx.s.hits;
+    job->total.texel_fetches += cx.s.texel_fetches; job->total.stack_overflows += cx.s.stack_overflows;
+    job->total.tex_clamped += cx.s.tex_clamped;
+    if (cx.s.max_stack > job->total.max_stack) job->total.max_stack = cx.s.max_stack;
+    pthread_mutex_unlock(&job->mu);
+    return NULL;
+}
+
+int orc_render(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+               const OrcMaterial *materials, uint32_t n_materials,
+               const OrcTexture *textures, uint32_t n_textures,
+               const OrcCamera *camera, const OrcOptions *opt,
+               float *hdr, uint8_t *rgba8, OrcStats *stats) {
+    /* renderer.rs:14-26 invariants */
+    if (!opt || opt->width == 0 || opt->height == 0) return -1;
+    if (opt->max_ray_depth == 0) return -2;
+    if (opt->samples == 0) return -3;
+    if (!tris || n_tris == 0 || !nodes || n_nodes == 0 || !materials || !camera) return -4;
+    Job job; memset(&job, 0, sizeof job);
+    job.sc.tris = tris; job.sc.n_tris = n_tris; job.sc.nodes = nodes; job.sc.n_nodes = n_nodes;
+    job.sc.materials = materials; job.sc.n_materials = n_materials;
+    job.sc.textures = textures; job.sc.n_textures = n_textures;
+    job.cam = camera; job.opt = *opt; job.hdr = hdr; job.rgba8 = rgba8;
+    uint64_t total = (uint64_t)opt->width * opt->height;
+    if (job.opt.pix_end == 0 || job.opt.pix_end > total) job.opt.pix_end = total;
+    if (job.opt.pix_begin > job.opt.pix_end) return -5;
+    uint64_t stride = job.opt.pix_stride ? job.opt.pix_stride : 1;
+    job.n_items = (job.opt.pix_end - job.opt.pix_begin + stride - 1) / stride;
+    long hw = sysconf(_SC_NPROCESSORS_ONLN);
+    uint32_t T = opt->threads ? opt->threads : (uint32_t)(hw > 0 ? hw : 1);
+    if (T > 1024) T = 1024;
+    job.block = job.n_items / T; if (job.block == 0) job.block = 1;      /* cpu.rs:22 */
+    pthread_mutex_init(&job.mu, NULL);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
+    for (uint32_t i = 0; i < T; i++) pthread_create(&th[i], NULL, worker, &job);
+    for (uint32_t i = 0; i < T; i++) pthread_join(th[i], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    pthread_mutex_destroy(&job.mu);
+    if (stats) {
+        *stats = job.total;
+        stats->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        stats->threads_used = T;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* scene.rs:181-194, mat4.rs:25-44 -- camera                                  */
+/* ------------------------------------------------------------------------- */
+void orc_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg, OrcCamera *out) {
+    /* f32::to_radians = x * (PI/180) with the f32 constant 0.017453292 */
+    const float RADS_PER_DEG = 0.017453292519943295769236907684886f;
+    float yaw = yaw_deg * RADS_PER_DEG, pitch = pitch_deg * RADS_PER_DEG;
+    v3 direction = V3(cosf(yaw) * cosf(pitch), sinf(pitch), sinf(yaw) * cosf(pitch));
+    v3 world_up = V3(0.0f, 1.0f, 0.0f);
+    v3 pos = V3(position[0], position[1], position[2]);
+    v3 forward = v_normalized(direction);
+    v3 right = v_normalized(v_cross(world_up, forward));
+    v3 up = v_cross(forward, right);
+    /* Mat4f::look_at(position, position + forward, up) */
+    v3 from = pos, to = v_add(pos, forward);
+    v3 f = v_normalized(v_sub(from, to));
+    v3 r = v_normalized(v_cross(up, f));
+    v3 u = v_cross(f, r);
+    memset(out, 0, sizeof *out);
+    out->look_at[0][0] = r.x; out->look_at[0][1] = r.y; out->look_at[0][2] = r.z; out->look_at[0][3] = 0.0f;
+    out->look_at[1][0] = u.x; out->look_at[1][1] = u.y; out->look_at[1][2] = u.z; out->look_at[1][3] = 0.0f;
+    out->look_at[2][0] = f.x; out->look_at[2][1] = f.y; out->look_at[2][2] = f.z; out->look_at[2][3] = 0.0f;
+    out->look_at[3][0] = from.x; out->look_at[3][1] = from.y; out->look_at[3][2] = from.z; out->look_at[3][3] = 1.0f;
+    out->position = pos;
+}
+
+/* ------------------------------------------------------------------------- */
+/* bvh.rs:13-204 -- binned-SAH builder, restated pass for pass                */
+/* ------------------------------------------------------------------------- */
+static inline OrcNode node_default(void) {             /* bvh.rs:173-182 */
+    OrcNode n;
+    n.bounds_min = V3(ORC_F32_MAX, ORC_F32_MAX, ORC_F32_MAX); n.first_tri_or_child = 0;
+    n.bounds_max = V3(-ORC_F32_MAX, -ORC_F32_MAX, -ORC_F32_MAX); n.num_tris = 0;
+    return n;
+}
+static inline void grow_by_tri(OrcNode *n, const OrcTriangle *t) { /* bvh.rs:185-194 */
+    for (int k = 0; k < 3; k++) {
+        const float *p = &t->vertices[k].position.x;
+        float *mn = &n->bounds_min.x, *mx = &n->bounds_max.x;
+        for (int i = 0; i < 3; i++) { mn[i] = fminf(mn[i], p[i]); mx[i] = fmaxf(mx[i], p[i]); }
+    }
+}
+static inline float surface_area(const OrcNode *n) {   /* bvh.rs:196-203 (half area, T14) */
+    v3 e = v_sub(n->bounds_max, n->bounds_min);
+    return (e.x * e.z) + (e.x * e.y) + (e.z * e.y);
+}
+static inline float bounds_mid_axis(const OrcTriangle *t, int axis) { /* scene.rs:114-126 */
+    float mn = ORC_F32_MAX, mx = -ORC_F32_MAX;
+    for (int k = 0; k < 3; k++) {
+        float p = (&t->vertices[k].position.x)[axis];
+        mn = fminf(mn, p); mx = fmaxf(mx, p);
+    }
+    return (mn + mx) / 2.0f;
+}
+typedef struct { OrcTriangle *tris; OrcNode *nodes; uint32_t n_nodes, cap; int err; } Build;
+
+static float evaluate_sah(const Build *b, const OrcNode *node, int axis, float pos) { /* bvh.rs:138-161 */
+    OrcNode left = node_default(), right = node_default();
+    for (uint32_t i = 0; i < node->num_tris; i++) {
+        const OrcTriangle *t = &b->tris[node->first_tri_or_child + i];
+        if (bounds_mid_axis(t, axis) < pos) { grow_by_tri(&left, t); left.num_tris += 1; }
+        else { grow_by_tri(&right, t); right.num_tris += 1; }
+    }
+    float cost = (float)left.num_tris * surface_area(&left) + (float)right.num_tris * surface_area(&right);
+    if (cost > 0.0f) return cost;                      /* NaN (empty side: 0*inf) -> f32::MAX */
+    return ORC_F32_MAX;
+}
+
+static void split_node(Build *b, uint32_t index) {     /* bvh.rs:56-136; explicit stack replaces recursion */
+    uint32_t *todo = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(b->cap + 2));
+    size_t top = 0;
+    todo[top++] = index;
+    while (top) {
+        uint32_t idx = todo[--top];
+        uint32_t used_nodes = b->n_nodes;
+        OrcNode *node = &b->nodes[idx];
+        float parent_cost = (float)node->num_tris * surface_area(node);
+        int best_axis = 0; float best_pos = 0.0f, best_cost = ORC_F32_MAX;
+        for (int axis = 0; axis < 3; axis++) {
+            float cmin = ORC_F32_MAX, cmax = -ORC_F32_MAX;   /* f32::MIN == -f32::MAX */
+            for (uint32_t i = 0; i < node->num_tris; i++) {
+                float m = bounds_mid_axis(&b->tris[node->first_tri_or_child + i], axis);
+                cmin = fminf(cmin, m); cmax = fmaxf(cmax, m);
+            }
+            if (cmin == cmax) continue;
+            float scale = (cmax - cmin) / 8.0f;
+            for (int i = 1; i < 8; i++) {
+                float pos = cmin + (float)i * scale;
+                float cost = evaluate_sah(b, node, axis, pos);
+                if (cost < best_cost) { best_axis = axis; best_pos = pos; best_cost = cost; }
+            }
+        }
+        if (best_cost >= parent_cost) continue;
+        uint32_t i = node->first_tri_or_child;
+        uint32_t j = i + node->num_tris - 1;
+        while (i <= j) {                                /* bvh.rs:99-108 */
+            if (bounds_mid_axis(&b->tris[i], best_axis) < best_pos) { i += 1; }
+            else {
+                OrcTriangle tmp = b->tris[i]; b->tris[i] = b->tris[j]; b->tris[j] = tmp;
+                if (j == 0) { b->err = -10; free(todo); return; }   /* Rust: u32 underflow panic */
+                j -= 1;
+            }
+        }
+        uint32_t a_count = i - node->first_tri_or_child;
+        if (a_count == 0 || a_count == node->num_tris) continue;
+        if (b->n_nodes + 2 > b->cap) { b->err = -11; free(todo); return; }
+        OrcNode a = node_default(), c = node_default();
+        a.first_tri_or_child = node->first_tri_or_child; a.num_tris = a_count;
+        c.first_tri_or_child = i; c.num_tris = node->num_tris - a_count;
+        node->first_tri_or_child = used_nodes; node->num_tris = 0;
+        for (uint32_t k = 0; k < a.num_tris; k++) grow_by_tri(&a, &b->tris[a.first_tri_or_child + k]);
+        for (uint32_t k = 0; k < c.num_tris; k++) grow_by_tri(&c, &b->tris[c.first_tri_or_child + k]);
+        b->nodes[b->n_nodes++] = a;
+        b->nodes[b->n_nodes++] = c;
+        /* bvh.rs:134-135 recurses left then right, and node indices are handed out in
+         * that depth-first order -- but each call allocates its children at the CURRENT
+         * end of the vector, so the left subtree must be finished before the right child
+         * is split: push right first, then left (LIFO). */
+        todo[top++] = used_nodes + 1;
+        todo[top++] = used_nodes;
+    }
+    free(todo);
+}
+
+int orc_bvh_build(OrcTriangle *tris, uint32_t n_tris, OrcNode *nodes_out, uint32_t nodes_cap, uint32_t *n_nodes_out) {
+    if (!tris || !nodes_out || nodes_cap == 0) return -1;
+    if (n_tris == 0) return -12;                       /* the reference panics on an empty scene (bvh.rs:100 underflow) */
+    Build b = {tris, nodes_out, 0, nodes_cap, 0};
+    OrcNode root = node_default();                     /* bvh.rs:18-24 */
+    for (uint32_t i = 0; i < n_tris; i++) grow_by_tri(&root, &tris[i]);
+    root.num_tris = n_tris;
+    b.nodes[b.n_nodes++] = root;
+    split_node(&b, 0);
+    if (n_nodes_out) *n_nodes_out = b.n_nodes;
+    return b.err;
+}

@@ -1,0 +1,143 @@
+/*
+ * pt_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's rayon CPU path tracer
+ * (MiksuNy/rust_ray_tracing, src/renderer/backend/cpu.rs + cpu/ray.rs and the
+ * math / scene / bvh pieces they call).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (rust_ray_tracing_amd/csrc, libmipt.so) never links, includes or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" by the reference -- the reference ships no
+ * tests, golden vectors or fixtures and cannot be compiled here
+ * (Rust toolchain absent).  The oracle is pinned instead by the
+ * hand-derived known answers of SURVEY.md Appendix B (tests/test_oracle_kat.py)
+ * and by goldens it emitted itself (tests/golden/).
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- PODs: byte-identical to the reference's #[repr(C, align(16))] structs ---- */
+typedef struct { float x, y, z; } OrcVec3;                    /* math/vec3.rs:55-59 */
+
+typedef struct {                                              /* scene.rs:87-94   */
+    OrcVec3 position; float tex_coord_x;
+    OrcVec3 normal;   float tex_coord_y;
+} OrcVertex;                                                  /* 32 B */
+
+typedef struct {                                              /* scene.rs:97-103  */
+    OrcVertex vertices[3];
+    uint32_t  material_id;
+    uint8_t   _pad[12];
+} OrcTriangle;                                                /* 112 B */
+
+typedef struct {                                              /* bvh.rs:164-171   */
+    OrcVec3  bounds_min; uint32_t first_tri_or_child;
+    OrcVec3  bounds_max; uint32_t num_tris;
+} OrcNode;                                                    /* 32 B */
+
+typedef struct {                                              /* scene.rs:129-146 */
+    OrcVec3 base_color;    float transmission;
+    OrcVec3 specular_tint; float ior;
+    OrcVec3 emission;      float roughness;
+    float metallic, transparency;
+    uint32_t base_color_tex_id, transparency_tex_id, roughness_tex_id,
+             metallic_tex_id, emission_tex_id, normal_tex_id;
+} OrcMaterial;                                                /* 80 B */
+
+typedef struct {                                              /* gpu.rs:480-486   */
+    float   look_at[4][4];       /* data[col][row], mat4.rs:6-10 */
+    OrcVec3 position; float _pad;
+} OrcCamera;                                                  /* 80 B */
+
+typedef struct {                                              /* texture.rs:4-10  */
+    uint32_t width, height;
+    const uint8_t *rgba8;        /* width*height*4, already v-flipped */
+} OrcTexture;
+
+enum { ORC_SEED_PIXEL_STREAM = 0,   /* cpu.rs:28-29           */
+       ORC_SEED_PER_SAMPLE   = 1 }; /* rt_compute.wgsl:102    */
+enum { ORC_LIBM_SHIM = 0,           /* deterministic cos/log10/pow (shared spec with the kernel) */
+       ORC_LIBM_HOST = 1 };         /* glibc cosf/log10f/powf = what the Rust binary would call  */
+
+typedef struct {
+    uint32_t width, height;          /* renderer.rs:100 output_image_dimensions */
+    uint32_t samples;                /* renderer.rs:98  */
+    uint32_t max_ray_depth;          /* renderer.rs:99  */
+    uint32_t seed_mode;              /* ORC_SEED_*      */
+    uint32_t cull;                   /* 0 = cpu/ray.rs:69-81 (no t-max cull); 1 = rt_compute.wgsl:341-349 */
+    uint32_t libm;                   /* ORC_LIBM_*      */
+    uint32_t threads;                /* 0 = hardware concurrency */
+    uint64_t pix_begin, pix_end;     /* pixel-index range (end 0 = width*height) */
+    uint32_t pix_stride;             /* 0/1 = every pixel */
+    uint32_t sample_begin;           /* PER_SAMPLE mode: first sample number (>=1), 0 -> 1 */
+    uint32_t stack_cap;              /* traversal stack entries; 0 -> 64 (reference: 32, ray.rs:85) */
+    uint32_t sum_only;               /* 1: hdr = sum over samples (no /samples), for sample-sharding */
+} OrcOptions;
+
+typedef struct {
+    uint64_t rays;            /* traverse_bvh invocations (ray.rs:150)                 */
+    uint64_t inner_steps;     /* inner-node visits (two child slab tests each)         */
+    uint64_t tri_tests;       /* intersect_tri calls                                   */
+    uint64_t hits;            /* rays that hit something                               */
+    uint64_t texel_fetches;   /* Texture::color_at calls                               */
+    uint64_t stack_overflows; /* pushes dropped because the stack was full             */
+    uint64_t max_stack;       /* deepest stack occupancy seen                          */
+    uint64_t tex_clamped;     /* texel index clamped (reference would panic, T10)      */
+    double   seconds;         /* wall time of the pixel loop                           */
+    uint32_t threads_used;
+    uint32_t _pad;
+} OrcStats;
+
+/* bvh.rs:13-161.  Reorders tris in place, writes <= 2*n-1 nodes. */
+int orc_bvh_build(OrcTriangle *tris, uint32_t n_tris, OrcNode *nodes_out,
+                  uint32_t nodes_cap, uint32_t *n_nodes_out);
+
+/* scene.rs:181-194 + mat4.rs:25-44 */
+void orc_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg,
+                          OrcCamera *out);
+
+/* cpu.rs:13-68.  hdr: width*height*3 f32 linear mean (or sum), may be NULL.
+ * rgba8: width*height*4, may be NULL.  Returns 0 or a negative error. */
+int orc_render(const OrcTriangle *tris, uint32_t n_tris,
+               const OrcNode *nodes, uint32_t n_nodes,
+               const OrcMaterial *materials, uint32_t n_materials,
+               const OrcTexture *textures, uint32_t n_textures,
+               const OrcCamera *camera, const OrcOptions *opt,
+               float *hdr, uint8_t *rgba8, OrcStats *stats);
+
+/* ---- small entry points for the known-answer tests ---- */
+uint32_t orc_pixel_seed(uint32_t index);                        /* cpu.rs:28-29 */
+uint32_t orc_sample_seed(uint32_t s, uint32_t x, uint32_t y);   /* rt_compute.wgsl:102 */
+uint32_t orc_xor_shift(uint32_t *state);                        /* math.rs:6-13 */
+float    orc_rand_f32(uint32_t *state);                         /* math.rs:22-24 */
+float    orc_rand_f32_nd(uint32_t *state, int libm);            /* math.rs:15-19 */
+void     orc_rand_in_unit_sphere(uint32_t *state, int libm, float out[3]); /* vec3.rs:66-68 */
+float    orc_intersect_node(const float o[3], const float d[3], const OrcNode *n); /* ray.rs:69-81 */
+/* ray.rs:19-67: out = {has_hit, t, u, v, front_face, nx,ny,nz, uvx,uvy, px,py,pz} */
+void     orc_intersect_tri(const float o[3], const float d[3], const OrcTriangle *t, float out[13]);
+void     orc_linear_to_srgb(const float in[3], int libm, float out[3]);  /* vec3.rs:80-90 */
+void     orc_quantize(const float in[3], uint8_t out[3]);       /* vec3.rs:262-270 */
+void     orc_texture_color_at(const OrcTexture *t, float u, float v, uint8_t out[4]); /* texture.rs:33-38 */
+void     orc_pixel_screen(uint32_t index, uint32_t w, uint32_t h, float out[2]); /* cpu.rs:31-35 */
+float    orc_shim_cosf(float x);
+float    orc_shim_log10f(float x);
+float    orc_shim_powf(float x, float y);
+/* trace one explicit ray (ray.rs:141-202); returns radiance in out[3] */
+void     orc_trace_ray(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+                       const OrcMaterial *materials, uint32_t n_materials,
+                       const OrcTexture *textures, uint32_t n_textures,
+                       const float o[3], const float d[3], uint32_t max_depth,
+                       uint32_t *rng, int cull, int libm, float out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

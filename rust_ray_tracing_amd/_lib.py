@@ -1,0 +1,142 @@
+"""ctypes binding of libmipt.so (include/mipt.h) -- the C ABI is the product boundary.
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C rust_ray_tracing_amd/csrc``).
+There is no fallback: if the shared object is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmipt.so")
+
+# ---- numpy views of the reference PODs (reference src/scene.rs:87-146, src/bvh.rs:164-171) ----
+VERTEX = np.dtype([("position", "<f4", 3), ("tex_coord_x", "<f4"), ("normal", "<f4", 3), ("tex_coord_y", "<f4")])
+TRIANGLE = np.dtype([("vertices", VERTEX, 3), ("material_id", "<u4"), ("_pad", "u1", 12)])
+NODE = np.dtype([("bounds_min", "<f4", 3), ("first_tri_or_child", "<u4"), ("bounds_max", "<f4", 3), ("num_tris", "<u4")])
+MATERIAL = np.dtype([
+    ("base_color", "<f4", 3), ("transmission", "<f4"), ("specular_tint", "<f4", 3), ("ior", "<f4"),
+    ("emission", "<f4", 3), ("roughness", "<f4"), ("metallic", "<f4"), ("transparency", "<f4"),
+    ("base_color_tex_id", "<u4"), ("transparency_tex_id", "<u4"), ("roughness_tex_id", "<u4"),
+    ("metallic_tex_id", "<u4"), ("emission_tex_id", "<u4"), ("normal_tex_id", "<u4")])
+CAMERA = np.dtype([("look_at", "<f4", (4, 4)), ("position", "<f4", 3), ("_pad", "<f4")])
+assert VERTEX.itemsize == 32 and TRIANGLE.itemsize == 112 and NODE.itemsize == 32
+assert MATERIAL.itemsize == 80 and CAMERA.itemsize == 80
+
+NO_TEXTURE = 0xFFFFFFFF
+
+SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
+TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
+FLAG_COUNT, FLAG_PACKED, FLAG_SUM = 1, 2, 4
+
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_SCENE_LIMIT, ERR_BVH, ERR_IO, ERR_STACK = 0, -1, -2, -3, -4, -5, -6
+
+
+class MiptTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba8", C.c_void_p)]
+
+
+class MiptSceneDesc(C.Structure):
+    _fields_ = [("tris", C.c_void_p), ("n_tris", C.c_uint32),
+                ("nodes", C.c_void_p), ("n_nodes", C.c_uint32),
+                ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+                ("textures", C.POINTER(MiptTexture)), ("n_textures", C.c_uint32)]
+
+
+class MiptOptions(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
+                ("max_ray_depth", C.c_uint32), ("seed_mode", C.c_uint32), ("traversal", C.c_uint32),
+                ("flags", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32),
+                ("sample_begin", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+
+
+class MiptStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("rays", C.c_uint64), ("inner_steps", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("texel_fetches", C.c_uint64),
+                ("stack_overflows", C.c_uint64), ("tex_clamped", C.c_uint64), ("max_stack", C.c_uint64),
+                ("pixels", C.c_uint64), ("reserved", C.c_uint64 * 6)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/mipt.h declares (tests/test_abi.py checks the list against the header)
+EXPORTS = [
+    "mipt_scene_create", "mipt_scene_destroy", "mipt_render", "mipt_render_device",
+    "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_bvh_build",
+    "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
+    "mipt_device_count", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmipt.so once.  torch (if importable) is imported first so that libmipt binds to
+    the HIP runtime torch already loaded (same SONAME libamdhip64.so.7): device pointers of torch
+    tensors are then valid in our launches."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C rust_ray_tracing_amd/csrc). "
+                          "There is no CPU fallback for the MI355X backend.")
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, u32, u64, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
+    lib.mipt_scene_create.argtypes = [C.POINTER(MiptSceneDesc), C.c_int, C.POINTER(vp)]
+    lib.mipt_scene_create.restype = C.c_int
+    lib.mipt_scene_destroy.argtypes = [vp]
+    lib.mipt_scene_destroy.restype = None
+    lib.mipt_render.argtypes = [vp, vp, C.POINTER(MiptOptions), vp, vp, C.POINTER(MiptStats)]
+    lib.mipt_render.restype = C.c_int
+    lib.mipt_render_device.argtypes = [vp, vp, C.POINTER(MiptOptions), vp, vp, vp, C.POINTER(MiptStats)]
+    lib.mipt_render_device.restype = C.c_int
+    lib.mipt_packed_pixels.argtypes = [u32, u32, u32]
+    lib.mipt_packed_pixels.restype = u64
+    lib.mipt_unpack_tiles.argtypes = [vp, u32, u32, u32, vp, vp]
+    lib.mipt_unpack_tiles.restype = C.c_int
+    lib.mipt_tonemap_device.argtypes = [vp, u64, f32, vp, vp]
+    lib.mipt_tonemap_device.restype = C.c_int
+    lib.mipt_bvh_build.argtypes = [vp, u32, vp, u32, C.POINTER(u32), u32]
+    lib.mipt_bvh_build.restype = C.c_int
+    lib.mipt_camera_from_pose.argtypes = [C.POINTER(f32 * 3), f32, f32, vp]
+    lib.mipt_camera_from_pose.restype = C.c_int
+    lib.mipt_material_default.argtypes = [vp]
+    lib.mipt_material_default.restype = None
+    lib.mipt_last_error.argtypes = []
+    lib.mipt_last_error.restype = C.c_char_p
+    lib.mipt_abi_version.argtypes = []
+    lib.mipt_abi_version.restype = C.c_int
+    lib.mipt_device_count.argtypes = []
+    lib.mipt_device_count.restype = C.c_int
+    lib.mipt_obj_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.mipt_obj_load.restype = C.c_int
+    lib.mipt_obj_free.argtypes = [vp]
+    lib.mipt_obj_free.restype = None
+    lib.mipt_obj_get.argtypes = [vp, C.POINTER(MiptSceneDesc), C.POINTER(C.POINTER(C.c_char_p))]
+    lib.mipt_obj_get.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class MiptError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = load().mipt_last_error()
+        super().__init__(f"{where} failed with status {code}: {msg.decode() if msg else ''}")
+
+
+def check(code: int, where: str) -> None:
+    if code != 0:
+        raise MiptError(code, where)
+
+
+def ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)

@@ -1,0 +1,420 @@
+// mipt_api.cpp -- the extern "C" boundary of libmipt.so (include/mipt.h): scene upload into the
+// HBM layout of pt_kernel.h, render dispatch, status / error plumbing.  Host C++ only; every
+// device operation is stream-ordered HIP.  There is deliberately no CPU rendering path here:
+// without a HIP device the entry points return MIPT_ERR_HIP.
+#include "../../include/mipt.h"
+#include "pt_kernel.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(MiptVec3) == 12, "Vec3f");
+static_assert(sizeof(MiptVertex) == 32, "Vertex");
+static_assert(sizeof(MiptTriangle) == 112 && offsetof(MiptTriangle, material_id) == 96, "Triangle");
+static_assert(sizeof(MiptNode) == 32 && offsetof(MiptNode, first_tri_or_child) == 12 &&
+                  offsetof(MiptNode, bounds_max) == 16 && offsetof(MiptNode, num_tris) == 28, "Node");
+static_assert(sizeof(MiptMaterial) == 80 && offsetof(MiptMaterial, ior) == 28 && offsetof(MiptMaterial, emission) == 32 &&
+                  offsetof(MiptMaterial, roughness) == 44 && offsetof(MiptMaterial, base_color_tex_id) == 56, "Material");
+static_assert(sizeof(MiptCamera) == 80 && offsetof(MiptCamera, position) == 64, "UniformCamera");
+static_assert(sizeof(mipt::DevMaterial) == 32 && sizeof(mipt::DevTexture) == 16, "device records");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(MIPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));          \
+    } while (0)
+
+} // namespace
+
+void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+
+struct MiptScene {
+    int device = 0;
+    mipt::DevScene dev{};
+    void *d_pairs = nullptr, *d_tri_pos = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_texs = nullptr,
+         *d_texels = nullptr;
+    // workspace
+    mipt::DevStats *d_stats = nullptr;
+    uint32_t *d_ovf = nullptr;
+    size_t ovf_waves = 0;
+    float *d_hdr = nullptr;
+    size_t hdr_floats = 0;
+    uint8_t *d_rgba = nullptr;
+    size_t rgba_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 0;
+    uint32_t max_leaf = 0;
+};
+
+namespace {
+
+void free_scene(MiptScene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    void *ptrs[] = {s->d_pairs, s->d_tri_pos, s->d_tri_attr, s->d_mats, s->d_texs, s->d_texels,
+                    s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+template <class T>
+int upload(void **dst, const std::vector<T> &src, size_t min_bytes = 16) {
+    size_t bytes = src.size() * sizeof(T);
+    size_t alloc = bytes < min_bytes ? min_bytes : bytes;
+    HIP_TRY(hipMalloc(dst, alloc));
+    if (bytes) HIP_TRY(hipMemcpy(*dst, src.data(), bytes, hipMemcpyHostToDevice));
+    return MIPT_OK;
+}
+
+int ensure(void **p, size_t *have, size_t want_bytes) {
+    if (*have >= want_bytes && *p) return MIPT_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(p, want_bytes));
+    *have = want_bytes;
+    return MIPT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mipt_last_error(void) { return g_err.c_str(); }
+int mipt_abi_version(void) { return MIPT_ABI_VERSION; }
+
+int mipt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(MIPT_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+void mipt_material_default(MiptMaterial *m) {        // scene.rs:148-167
+    if (!m) return;
+    m->base_color = {0.8f, 0.8f, 0.8f}; m->transmission = 0.0f;
+    m->specular_tint = {1.0f, 1.0f, 1.0f}; m->ior = 1.45f;
+    m->emission = {0.0f, 0.0f, 0.0f}; m->roughness = 1.0f;
+    m->metallic = 0.0f; m->transparency = 1.0f;
+    m->base_color_tex_id = m->transparency_tex_id = m->roughness_tex_id = m->metallic_tex_id =
+        m->emission_tex_id = m->normal_tex_id = UINT32_MAX;
+}
+
+int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
+    if (!desc || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
+    *out = nullptr;
+    if (!desc->tris || desc->n_tris == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no triangles (the reference panics in BVH::build)");
+    if (!desc->nodes || desc->n_nodes == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no BVH nodes");
+    if (!desc->materials || desc->n_materials == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no materials");
+    if (desc->n_textures && !desc->textures) return fail(MIPT_ERR_INVALID_ARG, "n_textures > 0 but textures == NULL");
+    if (desc->n_tris > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, "%u triangles exceed the 2^25 device-format limit", desc->n_tris);
+    if ((desc->n_nodes & 1u) == 0u) return fail(MIPT_ERR_BVH, "node count %u is even: children are pushed in pairs after the root (bvh.rs:131-132)", desc->n_nodes);
+    const uint32_t n_pairs = (desc->n_nodes - 1u) / 2u;
+    if (n_pairs > mipt::kMaxPairs) return fail(MIPT_ERR_SCENE_LIMIT, "%u node pairs exceed the 2^24 device-format limit", n_pairs);
+
+    // ---- validate and re-base the BVH: pair[k] = {nodes[2k+1], nodes[2k+2]} ----
+    uint32_t max_leaf = 0;
+    for (uint32_t i = 0; i < desc->n_nodes; i++) {
+        const MiptNode &n = desc->nodes[i];
+        if (n.num_tris > 0) {
+            if ((uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris)
+                return fail(MIPT_ERR_BVH, "leaf node %u covers triangles [%u, %u+%u) beyond n_tris=%u", i, n.first_tri_or_child, n.first_tri_or_child, n.num_tris, desc->n_tris);
+            if (n.num_tris > max_leaf) max_leaf = n.num_tris;
+        } else {
+            const uint32_t c = n.first_tri_or_child;
+            if ((c & 1u) == 0u || (uint64_t)c + 1u >= desc->n_nodes || c <= i)
+                return fail(MIPT_ERR_BVH, "inner node %u has child index %u (must be odd, > parent, and c+1 < n_nodes=%u)", i, c, desc->n_nodes);
+        }
+    }
+    std::vector<float4> pairs((size_t)n_pairs * 4);
+    for (uint32_t k = 0; k < n_pairs; k++) {
+        for (uint32_t w = 0; w < 2; w++) {
+            const MiptNode &n = desc->nodes[2 * k + 1 + w];
+            const uint32_t a = n.num_tris > 0 ? n.first_tri_or_child : (n.first_tri_or_child - 1u) / 2u;
+            float4 lo, hi;
+            lo.x = n.bounds_min.x; lo.y = n.bounds_min.y; lo.z = n.bounds_min.z; memcpy(&lo.w, &a, 4);
+            hi.x = n.bounds_max.x; hi.y = n.bounds_max.y; hi.z = n.bounds_max.z; memcpy(&hi.w, &n.num_tris, 4);
+            pairs[(size_t)k * 4 + w * 2 + 0] = lo;
+            pairs[(size_t)k * 4 + w * 2 + 1] = hi;
+        }
+    }
+    // ---- triangles: 48-B intersection stream + 64-B shading stream ----
+    std::vector<float4> tri_pos((size_t)desc->n_tris * 3 + 1);   // +1: the kernel's unconditional 4th float4 load
+    std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
+    for (uint32_t i = 0; i < desc->n_tris; i++) {
+        const MiptTriangle &t = desc->tris[i];
+        if (t.material_id >= desc->n_materials)
+            return fail(MIPT_ERR_INVALID_ARG, "triangle %u has material_id %u >= n_materials %u", i, t.material_id, desc->n_materials);
+        const MiptVec3 v0 = t.vertices[0].position, v1 = t.vertices[1].position, v2 = t.vertices[2].position;
+        // edge_1 = v_2 - v_1, edge_2 = v_3 - v_1 (ray.rs:24-25): one rounded f32 subtraction each,
+        // the same value the reference recomputes per test (-ffp-contract=off; no fusing possible here).
+        const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+        const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+        tri_pos[(size_t)i * 3 + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
+        tri_pos[(size_t)i * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
+        tri_pos[(size_t)i * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+        const MiptVec3 n0 = t.vertices[0].normal, n1 = t.vertices[1].normal, n2 = t.vertices[2].normal;
+        float mid;
+        memcpy(&mid, &t.material_id, 4);
+        tri_attr[(size_t)i * 4 + 0] = make_float4(n0.x, n0.y, n0.z, n1.x);
+        tri_attr[(size_t)i * 4 + 1] = make_float4(n1.y, n1.z, n2.x, n2.y);
+        tri_attr[(size_t)i * 4 + 2] = make_float4(n2.z, t.vertices[0].tex_coord_x, t.vertices[0].tex_coord_y, t.vertices[1].tex_coord_x);
+        tri_attr[(size_t)i * 4 + 3] = make_float4(t.vertices[1].tex_coord_y, t.vertices[2].tex_coord_x, t.vertices[2].tex_coord_y, mid);
+    }
+    tri_pos[(size_t)desc->n_tris * 3] = make_float4(0, 0, 0, 0);
+    // ---- materials / textures ----
+    std::vector<mipt::DevMaterial> mats(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const MiptMaterial &m = desc->materials[i];
+        if ((m.base_color_tex_id != UINT32_MAX && m.base_color_tex_id >= desc->n_textures) ||
+            (m.emission_tex_id != UINT32_MAX && m.emission_tex_id >= desc->n_textures))
+            return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
+        mats[i] = {{m.base_color.x, m.base_color.y, m.base_color.z}, m.base_color_tex_id,
+                   {m.emission.x, m.emission.y, m.emission.z}, m.emission_tex_id};
+    }
+    std::vector<mipt::DevTexture> texs(desc->n_textures);
+    uint64_t n_texels = 0;
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        const MiptTexture &t = desc->textures[i];
+        if (!t.rgba8 || t.width == 0 || t.height == 0) return fail(MIPT_ERR_INVALID_ARG, "texture %u is empty", i);
+        if (n_texels + (uint64_t)t.width * t.height > 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "texture pool exceeds 2^32 texels");
+        texs[i] = {(uint32_t)n_texels, t.width, t.height, 0u};
+        n_texels += (uint64_t)t.width * t.height;
+    }
+    std::vector<uint32_t> texels((size_t)n_texels);
+    for (uint32_t i = 0; i < desc->n_textures; i++)
+        memcpy(texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
+
+    // ---- device ----
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(MIPT_ERR_HIP, "HIP device %d not available (%d visible)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    MiptScene *s = new (std::nothrow) MiptScene();
+    if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
+    s->device = device_id;
+    s->max_leaf = max_leaf;
+    int rc;
+    if ((rc = upload(&s->d_pairs, pairs, 64)) || (rc = upload(&s->d_tri_pos, tri_pos)) || (rc = upload(&s->d_tri_attr, tri_attr)) ||
+        (rc = upload(&s->d_mats, mats, 32)) || (rc = upload(&s->d_texs, texs, 16)) || (rc = upload(&s->d_texels, texels, 16))) {
+        free_scene(s);
+        return rc;
+    }
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    s->n_cu = prop.multiProcessorCount;
+    if ((e = hipMalloc((void **)&s->d_stats, sizeof(mipt::DevStats))) != hipSuccess ||
+        (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
+        free_scene(s);
+        return fail(MIPT_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e));
+    }
+    s->dev.pairs = (const float4 *)s->d_pairs;
+    s->dev.tri_pos = (const float4 *)s->d_tri_pos;
+    s->dev.tri_attr = (const float4 *)s->d_tri_attr;
+    s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
+    s->dev.texs = (const mipt::DevTexture *)s->d_texs;
+    s->dev.texels = (const uint32_t *)s->d_texels;
+    s->dev.n_pairs = n_pairs; s->dev.n_tris = desc->n_tris; s->dev.n_mats = desc->n_materials; s->dev.n_texs = desc->n_textures;
+    // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0
+    s->dev.root_a = desc->nodes[0].num_tris > 0 ? desc->nodes[0].first_tri_or_child : 0u;
+    s->dev.root_n = desc->nodes[0].num_tris;
+    if (desc->nodes[0].num_tris == 0 && desc->nodes[0].first_tri_or_child != 1u) {
+        free_scene(s);
+        return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)");
+    }
+    *out = s;
+    return MIPT_OK;
+}
+
+void mipt_scene_destroy(MiptScene *scene) { free_scene(scene); }
+
+uint64_t mipt_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_world) {
+    if (tile_world == 0) tile_world = 1;
+    const uint64_t tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    return ((tiles + tile_world - 1u) / tile_world) * 64ull;
+}
+
+static int validate_options(const MiptOptions *opt) {
+    if (!opt) return fail(MIPT_ERR_INVALID_ARG, "options == NULL");
+    // Renderer::new (renderer.rs:15-26)
+    if (opt->width == 0 || opt->height == 0) return fail(MIPT_ERR_INVALID_ARG, "Width and height must be greater than 0");
+    if (opt->max_ray_depth == 0) return fail(MIPT_ERR_INVALID_ARG, "Max ray depth must be greater than 0");
+    if (opt->samples == 0) return fail(MIPT_ERR_INVALID_ARG, "Sample count must be greater than 0");
+    // seed wrap / absorbing zero seed: index + 87636354 must stay below 2^31
+    if ((uint64_t)opt->width * opt->height >= 2147483648ull - 87636354ull)
+        return fail(MIPT_ERR_INVALID_ARG, "width*height too large for the reference's 32-bit pixel seed");
+    if (opt->seed_mode > MIPT_SEED_PER_SAMPLE) return fail(MIPT_ERR_INVALID_ARG, "unknown seed_mode %u", opt->seed_mode);
+    if (opt->traversal > MIPT_TRAVERSAL_CULLED) return fail(MIPT_ERR_INVALID_ARG, "unknown traversal %u", opt->traversal);
+    const uint32_t world = opt->tile_world ? opt->tile_world : 1u;
+    if (opt->tile_rank >= world) return fail(MIPT_ERR_INVALID_ARG, "tile_rank %u >= tile_world %u", opt->tile_rank, world);
+    if ((opt->flags & MIPT_FLAG_SUM) && opt->seed_mode != MIPT_SEED_PER_SAMPLE && opt->sample_begin > 1)
+        return fail(MIPT_ERR_INVALID_ARG, "sample_begin needs MIPT_SEED_PER_SAMPLE (the pixel stream cannot be entered mid-way)");
+    for (uint32_t r : opt->reserved)
+        if (r) return fail(MIPT_ERR_INVALID_ARG, "reserved option fields must be 0");
+    return MIPT_OK;
+}
+
+int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                       float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats) {
+    if (!scene || !camera) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_device: null scene or camera");
+    int rc = validate_options(opt);
+    if (rc) return rc;
+    if (!d_hdr_rgb) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_device: d_hdr_rgb == NULL");
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+
+    const uint32_t world = opt->tile_world ? opt->tile_world : 1u;
+    const bool packed = (opt->flags & MIPT_FLAG_PACKED) != 0 && world > 1;
+    if (d_rgba8 && (packed || (opt->flags & MIPT_FLAG_SUM)))
+        return fail(MIPT_ERR_INVALID_ARG, "RGBA8 output needs a full-frame mean buffer (not PACKED / SUM)");
+
+    mipt::DevParams pr{};
+    pr.width = opt->width; pr.height = opt->height; pr.samples = opt->samples; pr.max_depth = opt->max_ray_depth;
+    pr.seed_mode = opt->seed_mode;
+    pr.sample_begin = opt->sample_begin ? opt->sample_begin : 1u;
+    pr.sum_only = (opt->flags & MIPT_FLAG_SUM) ? 1u : 0u;
+    pr.packed = packed ? 1u : 0u;
+    pr.tile_rank = opt->tile_rank; pr.tile_world = world;
+    pr.tiles_x = (opt->width + 7u) / 8u; pr.tiles_y = (opt->height + 7u) / 8u;
+    const uint64_t tiles = (uint64_t)pr.tiles_x * pr.tiles_y;
+    // tiles owned by this rank: t in [0, tiles) with t % world == rank
+    pr.n_local_tiles = (uint32_t)((tiles + world - 1u - opt->tile_rank) / world);
+    pr.total_work = (unsigned long long)pr.n_local_tiles * 64ull;
+    pr.aspect = (float)opt->width / (float)opt->height;       // cpu.rs:34
+    pr.samples_f = (float)opt->samples;                       // cpu.rs:60
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) pr.cam[c * 3 + r] = camera->look_at[c][r];
+    pr.cam[9] = camera->position.x; pr.cam[10] = camera->position.y; pr.cam[11] = camera->position.z;
+    pr.hdr = d_hdr_rgb;
+    pr.stats = scene->d_stats;
+
+    const bool count = (opt->flags & MIPT_FLAG_COUNT) != 0;
+    const bool cull = opt->traversal == MIPT_TRAVERSAL_CULLED;
+    int bpc = mipt::trace_blocks_per_cu(count, cull);
+    if (const char *env = getenv("MIPT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) bpc = v < bpc ? v : bpc; }
+    long long grid = (long long)scene->n_cu * bpc;
+    const long long need_blocks = (long long)((pr.total_work + mipt::kBlockThreads - 1) / mipt::kBlockThreads);
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    const size_t waves = (size_t)grid * mipt::kWavesPerBlock;
+    if (waves > scene->ovf_waves) {
+        if (scene->d_ovf) { (void)hipFree(scene->d_ovf); scene->d_ovf = nullptr; scene->ovf_waves = 0; }
+        HIP_TRY(hipMalloc((void **)&scene->d_ovf, waves * (size_t)mipt::kStackOvf * 64 * sizeof(uint32_t)));
+        scene->ovf_waves = waves;
+    }
+    pr.ovf = scene->d_ovf;
+
+    HIP_TRY(hipMemsetAsync(scene->d_stats, 0, sizeof(mipt::DevStats), stream));
+    HIP_TRY(hipEventRecord(scene->ev0, stream));
+    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, (int)grid, stream));
+    HIP_TRY(hipEventRecord(scene->ev1, stream));
+    if (d_rgba8) HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, (unsigned long long)opt->width * opt->height, 1.0f, d_rgba8, stream));
+    mipt::DevStats hs;
+    HIP_TRY(hipMemcpyAsync(&hs, scene->d_stats, sizeof hs, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->kernel_ms = ms;
+        stats->rays = hs.rays; stats->inner_steps = hs.inner_steps; stats->tri_tests = hs.tri_tests;
+        stats->hits = hs.hits; stats->texel_fetches = hs.texel_fetches; stats->stack_overflows = hs.stack_overflows;
+        stats->tex_clamped = hs.tex_clamped; stats->max_stack = hs.max_stack; stats->pixels = hs.pixels;
+    }
+    if (hs.stack_overflows)
+        return fail(MIPT_ERR_STACK, "traversal stack overflowed %llu times (capacity %d; the reference panics at 32, ray.rs:85)",
+                    hs.stack_overflows, mipt::kStackLds + mipt::kStackOvf);
+    return MIPT_OK;
+}
+
+int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                float *hdr_rgb, uint8_t *rgba8, MiptStats *stats) {
+    if (!scene) return fail(MIPT_ERR_INVALID_ARG, "mipt_render: null scene");
+    int rc = validate_options(opt);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    const uint32_t world = opt->tile_world ? opt->tile_world : 1u;
+    const bool packed = (opt->flags & MIPT_FLAG_PACKED) != 0 && world > 1;
+    const uint64_t n_pix = (uint64_t)opt->width * opt->height;
+    const uint64_t n_out = packed ? mipt_packed_pixels(opt->width, opt->height, world) : n_pix;
+    size_t have = scene->hdr_floats * sizeof(float);
+    if ((rc = ensure((void **)&scene->d_hdr, &have, (size_t)n_out * 3 * sizeof(float)))) return rc;
+    scene->hdr_floats = have / sizeof(float);
+    if (world > 1 && !packed) HIP_TRY(hipMemsetAsync(scene->d_hdr, 0, (size_t)n_out * 3 * sizeof(float), nullptr));
+    uint8_t *d_rgba = nullptr;
+    if (rgba8) {
+        if ((rc = ensure((void **)&scene->d_rgba, &scene->rgba_bytes, (size_t)n_pix * 4))) return rc;
+        d_rgba = scene->d_rgba;
+    }
+    rc = mipt_render_device(scene, camera, opt, scene->d_hdr, d_rgba, nullptr, stats);
+    if (rc && rc != MIPT_ERR_STACK) return rc;
+    if (hdr_rgb) HIP_TRY(hipMemcpy(hdr_rgb, scene->d_hdr, (size_t)n_out * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgba8) HIP_TRY(hipMemcpy(rgba8, scene->d_rgba, (size_t)n_pix * 4, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height, uint32_t tile_world,
+                      float *d_hdr_rgb, void *hip_stream) {
+    if (!d_packed_all || !d_hdr_rgb || width == 0 || height == 0 || tile_world == 0)
+        return fail(MIPT_ERR_INVALID_ARG, "mipt_unpack_tiles: bad argument");
+    HIP_TRY(mipt::launch_unpack_tiles(d_packed_all, width, height, tile_world, d_hdr_rgb, (hipStream_t)hip_stream));
+    return MIPT_OK;
+}
+
+int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint8_t *d_rgba8, void *hip_stream) {
+    if (!d_hdr_rgb || !d_rgba8 || n_pixels == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_tonemap_device: bad argument");
+    HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, n_pixels, divisor, d_rgba8, (hipStream_t)hip_stream));
+    return MIPT_OK;
+}
+
+// Camera::update_view + Mat4f::look_at (scene.rs:181-194, mat4.rs:25-44).  Host-only, once per
+// frame; sin/cos are the platform libm's, as in the reference.
+int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg, MiptCamera *out) {
+    if (!position || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_camera_from_pose: null argument");
+    struct V { float x, y, z; };
+    auto sub = [](V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto add = [](V a, V b) { return V{a.x + b.x, a.y + b.y, a.z + b.z}; };
+    auto cross = [](V a, V b) { return V{(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)}; };
+    auto norm = [](V a) { float l = sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); return V{a.x / l, a.y / l, a.z / l}; };
+    const float k = 0.017453292519943295769236907684886f;        // f32::to_radians
+    const float yaw = yaw_deg * k, pitch = pitch_deg * k;
+    const V direction{cosf(yaw) * cosf(pitch), sinf(pitch), sinf(yaw) * cosf(pitch)};
+    const V pos{position[0], position[1], position[2]};
+    const V forward = norm(direction);
+    const V right = norm(cross(V{0.0f, 1.0f, 0.0f}, forward));
+    const V up = cross(forward, right);
+    const V f = norm(sub(pos, add(pos, forward)));                // look_at(from, to = from + forward, up)
+    const V r = norm(cross(up, f));
+    const V u = cross(f, r);
+    memset(out, 0, sizeof *out);
+    out->look_at[0][0] = r.x; out->look_at[0][1] = r.y; out->look_at[0][2] = r.z;
+    out->look_at[1][0] = u.x; out->look_at[1][1] = u.y; out->look_at[1][2] = u.z;
+    out->look_at[2][0] = f.x; out->look_at[2][1] = f.y; out->look_at[2][2] = f.z;
+    out->look_at[3][0] = pos.x; out->look_at[3][1] = pos.y; out->look_at[3][2] = pos.z; out->look_at[3][3] = 1.0f;
+    out->position = {pos.x, pos.y, pos.z};
+    return MIPT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,69 @@
+// pt_kernel.h -- device-side scene layout and launch interface (internal to libmipt.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mipt {
+
+// ---- HBM layout (see DESIGN.md "Data layout") ------------------------------------------
+// pairs    : n_pairs x 64 B.  pair k = { nodes[2k+1], nodes[2k+2] } of the reference array
+//            (children are always pushed adjacently at odd indices, bvh.rs:121,131-132), each
+//            child kept in the reference's Node layout {min.xyz, a, max.xyz, n}: n = num_tris;
+//            a = first triangle (leaf) or the PAIR index of its own children (inner).
+// tri_pos  : n_tris x 48 B intersection stream {v0.xyz, e1.xyz, e2.xyz, 3 pad words},
+//            e1 = v1 - v0, e2 = v2 - v0 rounded once on the host exactly as ray.rs:24-25 does.
+// tri_attr : n_tris x 64 B shading stream {n0,n1,n2 (9 f32), uv0,uv1,uv2 (6 f32), material_id}.
+// mats     : n_materials x 32 B {base_color.xyz, base_color_tex_id, emission.xyz, emission_tex_id}
+//            -- the only Material fields cpu/ray.rs:162-176 reads.
+// texs     : n_textures x 16 B {texel offset into `texels`, width, height, 0}; texels = RGBA8 as u32.
+struct DevMaterial { float base[3]; uint32_t base_tex; float emis[3]; uint32_t emis_tex; };
+struct DevTexture { uint32_t offset, width, height, pad; };
+
+struct DevScene {
+    const float4 *pairs;
+    const float4 *tri_pos;
+    const float4 *tri_attr;
+    const DevMaterial *mats;
+    const DevTexture *texs;
+    const uint32_t *texels;
+    uint32_t n_pairs, n_tris, n_mats, n_texs;
+    uint32_t root_a, root_n;      // root node: leaf (root_n > 0: tris [root_a, root_a+root_n)) or inner (pair 0)
+};
+
+struct DevStats {                 // zeroed before every launch
+    unsigned long long queue;     // next work index
+    unsigned long long rays, inner_steps, tri_tests, hits, texel_fetches;
+    unsigned long long stack_overflows, tex_clamped, max_stack, pixels;
+};
+
+struct DevParams {
+    uint32_t width, height, samples, max_depth;
+    uint32_t seed_mode, sample_begin, sum_only, packed;
+    uint32_t tile_rank, tile_world, tiles_x, tiles_y;
+    uint32_t n_local_tiles, pad0;
+    unsigned long long total_work;          // n_local_tiles * 64
+    float aspect;                           // width as f32 / height as f32 (cpu.rs:34)
+    float samples_f;
+    float cam[12];                          // look_at columns 0..2 (xyz each), position
+    float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
+    uint32_t *ovf;                          // traversal-stack overflow area [wave][entry][lane]
+    DevStats *stats;
+};
+
+constexpr int kStackLds = 16;               // per-lane traversal-stack entries held in LDS
+constexpr int kStackOvf = 48;               // further entries spilled to HBM (rarely touched)
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlockThreads = 64 * kWavesPerBlock;
+constexpr uint32_t kMaxTris = 1u << 25;     // stack-entry encoding: 25-bit triangle index
+constexpr uint32_t kMaxPairs = 1u << 24;    // 24-bit pair index in the child-ref form
+
+// Launchers (stream-ordered; no allocation, no synchronisation inside).
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull,
+                        int grid_blocks, hipStream_t stream);
+int trace_blocks_per_cu(bool count, bool cull);     // occupancy query, cached
+hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t height,
+                               uint32_t tile_world, float *hdr, hipStream_t stream);
+hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,
+                          uint8_t *rgba8, hipStream_t stream);
+
+} // namespace mipt

@@ -1,0 +1,390 @@
+// pt_kernel.hip -- the gfx950 path-tracing megakernel.
+//
+// One persistent wave64 = 64 independent pixel streams.  A lane owns one pixel at a time and
+// runs that pixel's samples in sequence on one xorshift stream, because the reference's
+// per-pixel RNG makes sample k depend on how many numbers samples 0..k-1 drew
+// (reference src/renderer/backend/cpu.rs:28-29,37-58).  Lanes that run out of work are
+// refilled from a global queue with one wave-aggregated atomic (ballot + mbcnt compaction);
+// shading / ray generation is deferred until a ballot says enough lanes need it, so the
+// divergent "service" code runs with many lanes active instead of once per finished ray.
+//
+// Traversal restates Ray::traverse_bvh (reference src/renderer/backend/cpu/ray.rs:84-139)
+// step for step -- same visit order, same strict-< closest hit -- over re-based 64-byte child
+// pairs; the per-lane stack holds 32-bit entries, the first kStackLds of them in LDS
+// ([entry][lane] so a wave's access is one conflict-free ds_read/ds_write_b32).
+#include "pt_kernel.h"
+#include "pt_device_math.h"
+
+namespace mipt {
+
+namespace {
+
+constexpr float kMiss = 1e30f;                     // ray.rs:79,217
+constexpr uint32_t kNoTri = 0xffffffffu;
+constexpr uint32_t kFrontBit = 0x80000000u;
+constexpr uint32_t kNoTex = 0xffffffffu;
+
+enum : uint32_t {
+    ST_T = 0,   // traversing
+    ST_S = 1,   // traversal finished, needs shading
+    ST_G = 2,   // needs a camera ray for its next sample
+    ST_P = 3,   // needs a pixel
+    ST_X = 4    // queue exhausted, lane retired
+};
+
+// stack entry: inner -> pair index (bit31 = 0);
+// leaf -> bit31 | n << 25 | first_tri  (1 <= n <= 63);
+// leaf with n >= 64 -> bit31 | (pair*2 + which)  (n field 0: re-read (a, n) from the pair on pop)
+__device__ __forceinline__ uint32_t encode_child(uint32_t a, uint32_t n, uint32_t pair, uint32_t which) {
+    if (n == 0) return a;
+    if (n < 64u) return 0x80000000u | (n << 25) | a;
+    return 0x80000000u | (pair * 2u + which);
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ray.rs:69-81 (+ rt_compute.wgsl:348's t_near < max_distance when CULL)
+template <bool CULL>
+__device__ __forceinline__ float slab(V3 o, V3 d, float4 lo, float4 hi, float best) {
+    float tminx = (lo.x - o.x) / d.x, tminy = (lo.y - o.y) / d.y, tminz = (lo.z - o.z) / d.z;
+    float tmaxx = (hi.x - o.x) / d.x, tmaxy = (hi.y - o.y) / d.y, tmaxz = (hi.z - o.z) / d.z;
+    float t1x = fminf(tminx, tmaxx), t1y = fminf(tminy, tmaxy), t1z = fminf(tminz, tmaxz);
+    float t2x = fmaxf(tminx, tmaxx), t2y = fmaxf(tminy, tmaxy), t2z = fmaxf(tminz, tmaxz);
+    float t_near = fmaxf(fmaxf(t1x, t1y), t1z);
+    float t_far = fminf(fminf(t2x, t2y), t2z);
+    bool ok = (t_near <= t_far) && (t_far > 0.0f);
+    if (CULL) ok = ok && (t_near < best);
+    return ok ? t_near : kMiss;
+}
+
+// texture.rs:33-38; out-of-range indices (reference: panic) are clamped and counted
+__device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t tex, float u, float v, DevStats *st) {
+    DevTexture t = sc.texs[tex];
+    float fu = u - truncf(u), fv = v - truncf(v);                  // f32::fract
+    float fi = fu * (float)t.width, fj = fv * (float)t.height;
+    // Rust `as i32`: saturating, NaN -> 0
+    long long i = (fi != fi) ? 0ll : (fi >= 2147483648.0f ? 2147483647ll : (fi <= -2147483648.0f ? -2147483648ll : (long long)(int)fi));
+    long long j = (fj != fj) ? 0ll : (fj >= 2147483648.0f ? 2147483647ll : (fj <= -2147483648.0f ? -2147483648ll : (long long)(int)fj));
+    long long index = i + j * (long long)t.width;
+    long long n = (long long)t.width * (long long)t.height;
+    if (index < 0 || index >= n) {
+        index = index < 0 ? 0 : n - 1;
+        atomicAdd(&st->tex_clamped, 1ull);
+    }
+    uint32_t px = sc.texels[(size_t)t.offset + (size_t)index];
+    return mk((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f); // vec3.rs:252-260
+}
+
+} // namespace
+
+template <bool COUNT, bool CULL>
+__global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, DevParams pr) {
+    __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds][64];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wib = threadIdx.x >> 6;
+    uint32_t(*stk)[64] = s_stack[wib];
+    uint32_t *ovf = pr.ovf + ((size_t)blockIdx.x * kWavesPerBlock + wib) * (size_t)(kStackOvf * 64) + lane;
+
+    // ---- per-lane path state ----
+    uint32_t state = ST_P;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    V3 ray_color = mk(1, 1, 1), incoming = mk(0, 0, 0), emitted = mk(0, 0, 0), final_color = mk(0, 0, 0);
+    uint32_t rng = 0, pix = 0, slot = 0, sample = 0, bounces = 0;
+    float screen_x = 0, screen_y = 0;
+    // ---- per-lane traversal state ----
+    float best_t = kMiss, best_u = 0, best_v = 0;
+    uint32_t best_tri = kNoTri;
+    uint32_t tri_cur = 0, tri_end = 0, pair = 0, sp = 0;
+    // ---- counters (COUNT build only) ----
+    unsigned long long c_rays = 0, c_inner = 0, c_tris = 0, c_hits = 0, c_tex = 0;
+    uint32_t c_maxsp = 0, c_pixels = 0;
+
+    for (;;) {
+        const unsigned long long m_t = __ballot(state == ST_T);
+        const unsigned long long m_need = __ballot(state != ST_T && state != ST_X);
+        const uint32_t n_t = (uint32_t)__popcll(m_t), n_need = (uint32_t)__popcll(m_need);
+        if ((n_t | n_need) == 0u) break;
+
+        // ---------------- service: shade / finish pixel / fetch pixel / camera ray ------------
+        if (n_need != 0u && (n_t == 0u || n_need * 4u >= (n_t + n_need))) {
+            bool start_ray = false;
+            if (state == ST_S) {
+                bool path_done;
+                if (best_tri != kNoTri) {                                          // ray.rs:152-183
+                    const uint32_t tri = best_tri & ~kFrontBit;
+                    const float4 a0 = sc.tri_attr[(size_t)tri * 4 + 0], a1 = sc.tri_attr[(size_t)tri * 4 + 1];
+                    const float4 a2 = sc.tri_attr[(size_t)tri * 4 + 2], a3 = sc.tri_attr[(size_t)tri * 4 + 3];
+                    const float u = best_u, v = best_v;
+                    const float w = 1.0f - u - v;                                   // ray.rs:45
+                    V3 normal = mk(a0.x, a0.y, a0.z) * w + mk(a0.w, a1.x, a1.y) * u + mk(a1.z, a1.w, a2.x) * v;
+                    if (!(best_tri & kFrontBit)) normal = mk(-normal.x, -normal.y, -normal.z); // ray.rs:46-48
+                    const float uvx = ((a2.y * w) + (a2.w * u)) + (a3.y * v);       // ray.rs:50-53
+                    const float uvy = ((a2.z * w) + (a3.x * u)) + (a3.z * v);
+                    const V3 point = o + d * best_t;                                // ray.rs:60
+                    const DevMaterial m = sc.mats[__float_as_uint(a3.w)];           // ray.rs:153-154
+                    if (m.base_tex != kNoTex) {                                     // ray.rs:162-169
+                        ray_color = ray_color * texel_rgb(sc, m.base_tex, uvx, uvy, pr.stats);
+                        if (COUNT) c_tex++;
+                    } else {
+                        ray_color = ray_color * mk(m.base[0], m.base[1], m.base[2]);
+                    }
+                    if (m.emis_tex != kNoTex) {                                     // ray.rs:170-176
+                        emitted = emitted + texel_rgb(sc, m.emis_tex, uvx, uvy, pr.stats);
+                        if (COUNT) c_tex++;
+                    } else {
+                        emitted = emitted + mk(m.emis[0], m.emis[1], m.emis[2]);
+                    }
+                    incoming = incoming + emitted * ray_color;                       // ray.rs:177
+                    const V3 new_dir = normalized(normal + rand_in_unit_sphere(rng)); // ray.rs:179-180
+                    o = point + new_dir * 0.0001f;                                   // ray.rs:181
+                    d = new_dir;
+                    bounces += 1;
+                    if (COUNT) c_hits++;
+                    path_done = !(bounces < pr.max_depth);                           // ray.rs:147
+                } else {                                                             // ray.rs:184-193
+                    ray_color = ray_color * mk(1.0f, 1.0f, 1.0f);
+                    emitted = emitted + mk(1.0f, 1.0f, 1.0f);
+                    incoming = incoming + emitted * ray_color;
+                    path_done = true;
+                }
+                if (path_done) {
+                    const V3 res = (bounces == 0u) ? incoming : incoming / (float)bounces; // ray.rs:197-201
+                    final_color = final_color + res;                                 // cpu.rs:52
+                    sample += 1;
+                    if (sample < pr.samples) {
+                        state = ST_G;
+                    } else {
+                        if (!pr.sum_only) final_color = final_color / pr.samples_f;  // cpu.rs:60
+                        float *dst = pr.hdr + (size_t)slot * 3;
+                        dst[0] = final_color.x; dst[1] = final_color.y; dst[2] = final_color.z;
+                        c_pixels++;
+                        state = ST_P;
+                    }
+                } else {
+                    state = ST_T;                                                    // next bounce
+                    start_ray = true;
+                }
+            }
+            // ---- fetch a pixel: one atomic per wave, compacted over the lanes that need one ----
+            {
+                const unsigned long long m_p = __ballot(state == ST_P);
+                if (m_p != 0ull) {
+                    unsigned long long base = 0;
+                    const uint32_t leader = (uint32_t)__ffsll((long long)m_p) - 1u;
+                    if (lane == leader) base = atomicAdd(&pr.stats->queue, (unsigned long long)__popcll(m_p));
+                    base = __shfl(base, (int)leader);
+                    if (state == ST_P) {
+                        const unsigned long long wi = base + lane_rank(m_p);
+                        if (wi >= pr.total_work) {
+                            state = ST_X;
+                        } else {
+                            // 8x8 pixel tiles, round-robin over ranks: global tile = local*world + rank
+                            const uint32_t lt = (uint32_t)(wi >> 6), p = (uint32_t)wi & 63u;
+                            const uint32_t gt = lt * pr.tile_world + pr.tile_rank;
+                            const uint32_t px = (gt % pr.tiles_x) * 8u + (p & 7u);
+                            const uint32_t py = (gt / pr.tiles_x) * 8u + (p >> 3);
+                            if (px < pr.width && py < pr.height) {            // ragged edge tiles: skip, stay ST_P
+                                pix = py * pr.width + px;
+                                slot = pr.packed ? (uint32_t)wi : pix;
+                                rng = 987612486u * (pix + 87636354u);                 // cpu.rs:28-29
+                                const uint32_t y = pr.height - py;                    // cpu.rs:32
+                                screen_x = ((((float)px / (float)pr.width) * 2.0f) - 1.0f) * pr.aspect; // cpu.rs:33-34
+                                screen_y = (((float)y / (float)pr.height) * 2.0f) - 1.0f;               // cpu.rs:35
+                                final_color = mk(0.0f, 0.0f, 0.0f);
+                                sample = 0;
+                                state = ST_G;
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- camera ray (cpu.rs:37-50) ----
+            if (state == ST_G) {
+                if (pr.seed_mode != 0u) {                                             // rt_compute.wgsl:102
+                    const uint32_t px = pix % pr.width, py = pix / pr.width;
+                    rng = (pr.sample_begin + sample) * 6023u + (757283u * px + 872653746u * py);
+                }
+                const float jx = (rand_f32(rng) * 2.0f - 1.0f) * 0.0005f;
+                const float jy = (rand_f32(rng) * 2.0f - 1.0f) * 0.0005f;
+                const float rx = -screen_x + jx, ry = screen_y + jy, rz = 1.0f;
+                // Mat4f * Vec3f, upper-left 3x3, data[col][row] (mat4.rs:143-152)
+                const V3 dir = mk(pr.cam[0] * rx + pr.cam[3] * ry + pr.cam[6] * rz,
+                                  pr.cam[1] * rx + pr.cam[4] * ry + pr.cam[7] * rz,
+                                  pr.cam[2] * rx + pr.cam[5] * ry + pr.cam[8] * rz);
+                d = normalized(dir);
+                o = mk(pr.cam[9], pr.cam[10], pr.cam[11]);
+                ray_color = mk(1.0f, 1.0f, 1.0f);                                     // ray.rs:142-146
+                incoming = mk(0.0f, 0.0f, 0.0f);
+                emitted = mk(0.0f, 0.0f, 0.0f);
+                bounces = 0;
+                state = ST_T;
+                start_ray = true;
+            }
+            // ---- start traverse_bvh (ray.rs:84-88, HitInfo::default :214-226) ----
+            if (start_ray) {
+                best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;
+                sp = 0; pair = 0;
+                tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;   // root leaf (root_n > 0) or inner (empty range)
+                if (COUNT) c_rays++;
+            }
+            continue;   // re-evaluate the ballots
+        }
+
+        // ---------------- one traversal step per traversing lane ---------------------------------
+        if (state == ST_T) {
+            const bool leaf = tri_cur < tri_end;
+            const float4 *p = leaf ? (sc.tri_pos + (size_t)tri_cur * 3) : (sc.pairs + (size_t)pair * 4);
+            const float4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];   // tri_pos is padded by one float4
+            bool need_pop = false;
+            if (leaf) {                                                              // ray.rs:19-67, 90-99
+                const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+                const V3 rce2 = cross(d, e2);
+                const float det = dot(e1, rce2);
+                const float inv_det = 1.0f / det;
+                const V3 s = o - v0;
+                const float u = inv_det * dot(s, rce2);
+                const V3 sce1 = cross(s, e1);
+                const float v = inv_det * dot(d, sce1);
+                const float t = inv_det * dot(e2, sce1);
+                // ray.rs:56-59 verbatim boolean form: NaN u/v pass, NaN t fails;
+                // `!(det < 0.0 && det > -0.0)` is identically true and is dropped.
+                const bool has_hit = (t > 0.0f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
+                if (has_hit && t < best_t) {                                         // ray.rs:96 (strict <)
+                    best_t = t; best_u = u; best_v = v;
+                    best_tri = tri_cur | ((det > 0.0f) ? kFrontBit : 0u);            // ray.rs:39
+                }
+                if (COUNT) c_tris++;
+                tri_cur += 1;
+                need_pop = (tri_cur == tri_end);
+            } else {                                                                 // ray.rs:108-137
+                float d1 = slab<CULL>(o, d, r0, r1, best_t);
+                float d2 = slab<CULL>(o, d, r2, r3, best_t);
+                uint32_t a1 = __float_as_uint(r0.w), n1 = __float_as_uint(r1.w);
+                uint32_t a2 = __float_as_uint(r2.w), n2 = __float_as_uint(r3.w);
+                uint32_t w2 = 1u;
+                if (COUNT) c_inner++;
+                if (d1 > d2) {                                                       // ray.rs:120-123
+                    float td = d1; d1 = d2; d2 = td;
+                    uint32_t ta = a1; a1 = a2; a2 = ta;
+                    uint32_t tn = n1; n1 = n2; n2 = tn;
+                    w2 = 0u;
+                }
+                if (d1 == kMiss) {                                                   // ray.rs:124-130
+                    need_pop = true;
+                } else {
+                    if (d2 < kMiss) {                                                // ray.rs:133-136
+                        const uint32_t e = encode_child(a2, n2, pair, w2);
+                        if (sp < (uint32_t)kStackLds) stk[sp][lane] = e;
+                        else if (sp < (uint32_t)(kStackLds + kStackOvf)) ovf[(size_t)(sp - kStackLds) * 64] = e;
+                        if (sp < (uint32_t)(kStackLds + kStackOvf)) {
+                            sp += 1;
+                            if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
+                        } else {
+                            atomicAdd(&pr.stats->stack_overflows, 1ull);             // reference: panic (ray.rs:85)
+                        }
+                    }
+                    if (n1 > 0u) { tri_cur = a1; tri_end = a1 + n1; }                // ray.rs:131 node = child_1
+                    else { pair = a1; }
+                }
+            }
+            if (need_pop) {                                                          // ray.rs:100-105, 125-129
+                if (sp == 0u) {
+                    state = ST_S;
+                } else {
+                    sp -= 1;
+                    const uint32_t e = (sp < (uint32_t)kStackLds) ? stk[sp][lane] : ovf[(size_t)(sp - kStackLds) * 64];
+                    if (e & 0x80000000u) {
+                        uint32_t n = (e >> 25) & 63u, a = e & 0x01ffffffu;
+                        if (n == 0u) {                                               // big leaf: child-ref form
+                            const uint32_t ref = e & 0x7fffffffu;
+                            const float4 *q = sc.pairs + (size_t)(ref >> 1) * 4 + (ref & 1u) * 2;
+                            a = __float_as_uint(q[0].w); n = __float_as_uint(q[1].w);
+                        }
+                        tri_cur = a; tri_end = a + n;
+                    } else {
+                        pair = e; tri_cur = 0; tri_end = 0;
+                    }
+                }
+            }
+        }
+    }
+
+    if (COUNT) {
+        atomicAdd(&pr.stats->rays, c_rays);
+        atomicAdd(&pr.stats->inner_steps, c_inner);
+        atomicAdd(&pr.stats->tri_tests, c_tris);
+        atomicAdd(&pr.stats->hits, c_hits);
+        atomicAdd(&pr.stats->texel_fetches, c_tex);
+        atomicMax(&pr.stats->max_stack, (unsigned long long)c_maxsp);
+    }
+    if (c_pixels) atomicAdd(&pr.stats->pixels, (unsigned long long)c_pixels);
+}
+
+// ---- all-gathered rank-packed tile slices -> full frame -----------------------------------
+__global__ void unpack_tiles_kernel(const float *__restrict__ packed_all, uint32_t width, uint32_t height,
+                                    uint32_t world, uint32_t tiles_x, uint32_t n_local_tiles, float *__restrict__ hdr) {
+    const unsigned long long n = (unsigned long long)width * height;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t px = (uint32_t)(i % width), py = (uint32_t)(i / width);
+        const uint32_t gt = (py >> 3) * tiles_x + (px >> 3);
+        const uint32_t rank = gt % world, lt = gt / world;
+        const unsigned long long src = ((unsigned long long)rank * n_local_tiles + lt) * 64ull + ((py & 7u) * 8u + (px & 7u));
+        hdr[i * 3 + 0] = packed_all[src * 3 + 0];
+        hdr[i * 3 + 1] = packed_all[src * 3 + 1];
+        hdr[i * 3 + 2] = packed_all[src * 3 + 2];
+    }
+}
+
+// ---- cpu.rs:60-64 epilogue: (x scale) -> linear_to_srgb -> floor(x*255) clamp -> [r,g,b,255] ----
+__global__ void tonemap_kernel(const float *__restrict__ hdr, unsigned long long n, float divisor, uint32_t *__restrict__ rgba8) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        float r = hdr[i * 3 + 0], g = hdr[i * 3 + 1], b = hdr[i * 3 + 2];
+        if (divisor != 1.0f) { r = r / divisor; g = g / divisor; b = b / divisor; }   // cpu.rs:60
+        rgba8[i] = srgb_quantize(r) | (srgb_quantize(g) << 8) | (srgb_quantize(b) << 16) | 0xff000000u;
+    }
+}
+
+template <bool COUNT, bool CULL>
+static hipError_t launch_t(const DevScene &sc, const DevParams &pr, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int grid, hipStream_t stream) {
+    if (count) return cull ? launch_t<true, true>(sc, pr, grid, stream) : launch_t<true, false>(sc, pr, grid, stream);
+    return cull ? launch_t<false, true>(sc, pr, grid, stream) : launch_t<false, false>(sc, pr, grid, stream);
+}
+
+int trace_blocks_per_cu(bool count, bool cull) {
+    int n = 0;
+    hipError_t e;
+    if (count) e = cull ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<true, true>, kBlockThreads, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<true, false>, kBlockThreads, 0);
+    else e = cull ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<false, true>, kBlockThreads, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<false, false>, kBlockThreads, 0);
+    if (e != hipSuccess || n < 1) n = 1;
+    if (n > 8) n = 8;
+    return n;
+}
+
+hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t height, uint32_t world,
+                               float *hdr, hipStream_t stream) {
+    const uint32_t tiles_x = (width + 7u) / 8u, tiles_y = (height + 7u) / 8u;
+    const uint32_t n_local = (tiles_x * tiles_y + world - 1u) / world;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3(2048), dim3(256), 0, stream, packed_all, width, height, world,
+                       tiles_x, n_local, hdr);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor, uint8_t *rgba8, hipStream_t stream) {
+    hipLaunchKernelGGL(tonemap_kernel, dim3(2048), dim3(256), 0, stream, hdr, n_pixels, divisor,
+                       reinterpret_cast<uint32_t *>(rgba8));
+    return hipGetLastError();
+}
+
+} // namespace mipt

@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's Renderer / Scene API for the path-tracing hot path.
+
+Names, argument meaning and error behaviour follow the reference
+(src/renderer.rs:8-117, src/renderer/backend.rs:6-10, src/scene.rs:12-195):
+
+* ``Renderer.new(options)`` validates like ``Renderer::new`` and returns ``None`` (after logging
+  the reference's message) instead of raising;
+* ``Renderer.render(scene)`` dispatches on ``options.backend``; the new arm is
+  ``RendererBackend.MI355X`` which goes through the C ABI of libmipt.so;
+* ``Scene.load(path)`` / ``Scene.set_camera(camera)`` / ``Camera.update_view()`` as in scene.rs.
+
+Everything numerical happens behind the C ABI (include/mipt.h); this module only marshals.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+import sys
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+def log_error(msg: str) -> None:  # log.rs:22-29
+    print(f"[ERROR] {msg}", file=sys.stderr)
+
+
+def log_info(msg: str) -> None:  # log.rs:2-9
+    if os.environ.get("MIPT_LOG"):
+        print(f"[INFO] {msg}", file=sys.stderr)
+
+
+class RendererBackend(enum.Enum):  # renderer/backend.rs:6-10 + the new arm
+    GPU = "GPU"        # the reference's wgpu backend: not part of this build
+    CPU = "CPU"        # the reference's rayon backend: not part of this build (see oracle/ for tests)
+    MI355X = "MI355X"  # this build: gfx950 megakernel behind the C ABI
+
+
+@dataclass
+class RendererOptions:  # renderer.rs:96-116
+    samples: int = 1
+    max_ray_depth: int = 6
+    output_image_dimensions: Tuple[int, int] = (1920, 1080)
+    output_image_path: Optional[str] = None
+    backend: RendererBackend = RendererBackend.MI355X
+    is_realtime: bool = False
+    # MI355X-path extensions (MiptOptions)
+    seed_mode: int = L.SEED_PIXEL_STREAM
+    traversal: int = L.TRAVERSAL_REFERENCE
+    device_id: int = 0
+
+
+@dataclass
+class Camera:  # scene.rs:169-195
+    pitch: float = 0.0
+    yaw: float = 0.0
+    position: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    uniform: np.ndarray = field(default_factory=lambda: np.zeros((), dtype=L.CAMERA))
+
+    def update_view(self) -> None:
+        pos = (C.c_float * 3)(*[float(x) for x in self.position])
+        out = np.zeros((), dtype=L.CAMERA)
+        L.check(L.load().mipt_camera_from_pose(C.byref(pos), C.c_float(self.pitch), C.c_float(self.yaw), L.ptr(out)),
+                "mipt_camera_from_pose")
+        self.uniform = out
+
+
+def material_default() -> np.ndarray:  # scene.rs:148-167
+    m = np.zeros((), dtype=L.MATERIAL)
+    L.load().mipt_material_default(L.ptr(m))
+    return m
+
+
+class Scene:  # scene.rs:12-19
+    """tris / materials / textures / bvh / camera.  ``materials`` is name -> Material in id order."""
+
+    def __init__(self):
+        self.tris: np.ndarray = np.zeros(0, dtype=L.TRIANGLE)
+        self.materials: Dict[str, np.ndarray] = {}
+        self.textures: List[np.ndarray] = []      # each (h, w, 4) uint8, rows as Texture::load stores them
+        self.bvh_nodes: np.ndarray = np.zeros(0, dtype=L.NODE)
+        self.camera = Camera()
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device = -1
+
+    # -- construction ------------------------------------------------------------------------
+    @staticmethod
+    def load(path: str) -> Optional["Scene"]:  # scene.rs:22-36
+        lib = L.load()
+        obj = C.c_void_p()
+        rc = lib.mipt_obj_load(path.encode(), C.byref(obj))
+        if rc != 0:
+            log_error(lib.mipt_last_error().decode())
+            return None
+        try:
+            desc = L.MiptSceneDesc()
+            names = C.POINTER(C.c_char_p)()
+            L.check(lib.mipt_obj_get(obj, C.byref(desc), C.byref(names)), "mipt_obj_get")
+            sc = Scene()
+            sc.tris = np.ctypeslib.as_array(C.cast(desc.tris, C.POINTER(C.c_uint8)), (desc.n_tris * 112,)).copy().view(L.TRIANGLE)
+            sc.bvh_nodes = np.ctypeslib.as_array(C.cast(desc.nodes, C.POINTER(C.c_uint8)), (desc.n_nodes * 32,)).copy().view(L.NODE)
+            mats = np.ctypeslib.as_array(C.cast(desc.materials, C.POINTER(C.c_uint8)), (desc.n_materials * 80,)).copy().view(L.MATERIAL)
+            for i in range(desc.n_materials):
+                sc.materials[names[i].decode()] = mats[i].copy()
+            for i in range(desc.n_textures):
+                t = desc.textures[i]
+                px = np.ctypeslib.as_array(C.cast(t.rgba8, C.POINTER(C.c_uint8)), (t.height, t.width, 4)).copy()
+                sc.textures.append(px)
+            return sc
+        finally:
+            lib.mipt_obj_free(obj)
+
+    @staticmethod
+    def from_arrays(tris: np.ndarray, materials, textures=(), build_bvh: bool = True, threads: int = 0) -> "Scene":
+        """impl From<OBJ> for Scene (scene.rs:44-85) for already-expanded triangles."""
+        sc = Scene()
+        sc.tris = np.ascontiguousarray(tris, dtype=L.TRIANGLE).copy()
+        if isinstance(materials, dict):
+            sc.materials = {k: np.asarray(v, dtype=L.MATERIAL).reshape(()) for k, v in materials.items()}
+        else:
+            sc.materials = {f"material_{i}": np.asarray(m, dtype=L.MATERIAL).reshape(()) for i, m in enumerate(materials)}
+        sc.textures = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
+        if build_bvh:
+            sc.build_bvh(threads)
+        return sc
+
+    def build_bvh(self, threads: int = 0) -> None:  # BVH::build, bvh.rs:13-54
+        n = len(self.tris)
+        nodes = np.zeros(max(2 * n, 1), dtype=L.NODE)
+        count = C.c_uint32(0)
+        L.check(L.load().mipt_bvh_build(L.ptr(self.tris), n, L.ptr(nodes), len(nodes), C.byref(count), threads), "mipt_bvh_build")
+        self.bvh_nodes = nodes[: count.value].copy()
+        self.release()
+
+    def set_camera(self, camera: Camera) -> None:  # scene.rs:38-41
+        self.camera = camera
+        self.camera.update_view()
+
+    # -- device residency --------------------------------------------------------------------
+    def materials_array(self) -> np.ndarray:
+        return np.array([m for m in self.materials.values()], dtype=L.MATERIAL) if self.materials else np.zeros(0, dtype=L.MATERIAL)
+
+    def desc(self):
+        """MiptSceneDesc over this scene's arrays (keeps the backing arrays alive on the returned object)."""
+        mats = np.ascontiguousarray(self.materials_array())
+        texs = (L.MiptTexture * max(len(self.textures), 1))()
+        for i, t in enumerate(self.textures):
+            texs[i].width, texs[i].height, texs[i].rgba8 = t.shape[1], t.shape[0], t.ctypes.data
+        d = L.MiptSceneDesc(L.ptr(self.tris), len(self.tris), L.ptr(self.bvh_nodes), len(self.bvh_nodes),
+                            L.ptr(mats), len(mats), texs, len(self.textures))
+        d._keep = (mats, texs)
+        return d
+
+    def upload(self, device_id: int = 0) -> C.c_void_p:
+        if self._handle is not None and self._handle_device == device_id:
+            return self._handle
+        self.release()
+        h = C.c_void_p()
+        d = self.desc()
+        L.check(L.load().mipt_scene_create(C.byref(d), device_id, C.byref(h)), "mipt_scene_create")
+        self._handle, self._handle_device = h, device_id
+        return h
+
+    def release(self) -> None:
+        if self._handle is not None:
+            L.load().mipt_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def make_options(width, height, samples, max_ray_depth, seed_mode=L.SEED_PIXEL_STREAM, traversal=L.TRAVERSAL_REFERENCE,
+                 flags=0, tile_rank=0, tile_world=0, sample_begin=0) -> L.MiptOptions:
+    o = L.MiptOptions()
+    o.width, o.height, o.samples, o.max_ray_depth = width, height, samples, max_ray_depth
+    o.seed_mode, o.traversal, o.flags = seed_mode, traversal, flags
+    o.tile_rank, o.tile_world, o.sample_begin = tile_rank, tile_world, sample_begin
+    return o
+
+
+class Renderer:  # renderer.rs:8-85
+    def __init__(self, options: RendererOptions):
+        self.options = options
+        self.last_stats: Optional[dict] = None
+
+    @staticmethod
+    def new(options: RendererOptions) -> Optional["Renderer"]:  # renderer.rs:14-48
+        w, h = options.output_image_dimensions
+        if w == 0 or h == 0:
+            log_error("Width and height must be greater than 0")
+            return None
+        if options.max_ray_depth == 0:
+            log_error("Max ray depth must be greater than 0")
+            return None
+        if options.samples == 0:
+            log_error("Sample count must be greater than 0")
+            return None
+        if options.output_image_path is None and not options.is_realtime:
+            log_error("Output image path must be Some if realtime mode is disabled")
+            return None
+        if options.backend != RendererBackend.GPU and options.is_realtime:
+            log_error("Only the GPU backend is supported for realtime mode")
+            return None
+        return Renderer(options)
+
+    def render_buffers(self, scene: Scene, want_hdr: bool = True, want_rgba8: bool = True, flags: int = 0):
+        """The backend arm: (Renderer, &Scene) -> pixels.  Returns (hdr float32 [h,w,3] | None,
+        rgba8 uint8 [h,w,4] | None, stats dict)."""
+        o = self.options
+        if o.backend != RendererBackend.MI355X:
+            raise NotImplementedError(f"backend {o.backend.name} is not part of this build; use RendererBackend.MI355X")
+        w, h = o.output_image_dimensions
+        handle = scene.upload(o.device_id)
+        opt = make_options(w, h, o.samples, o.max_ray_depth, o.seed_mode, o.traversal, flags)
+        hdr = np.zeros((h, w, 3), dtype=np.float32) if want_hdr else None
+        rgba = np.zeros((h, w, 4), dtype=np.uint8) if want_rgba8 else None
+        st = L.MiptStats()
+        rc = L.load().mipt_render(handle, L.ptr(scene.camera.uniform), C.byref(opt),
+                                  L.ptr(hdr) if want_hdr else None, L.ptr(rgba) if want_rgba8 else None, C.byref(st))
+        L.check(rc, "mipt_render")
+        self.last_stats = st.as_dict()
+        return hdr, rgba, self.last_stats
+
+    def render(self, scene: Scene) -> bytes:  # renderer.rs:50-85 (offline arm)
+        if self.options.is_realtime:
+            raise NotImplementedError("the realtime window (gpu/window.rs) is out of scope")
+        _, rgba, stats = self.render_buffers(scene, want_hdr=False, want_rgba8=True)
+        log_info(f"Rendering took {stats['kernel_ms']:.1f} ms")
+        path = self.options.output_image_path
+        if path:
+            w, h = self.options.output_image_dimensions
+            write_ppm(path, rgba[:, :, :3]) if path.endswith(".ppm") else write_png_rgba8(path, rgba)
+            log_info(f"Succesfully wrote image data to '{path}'")
+        return rgba.tobytes()
+
+
+def write_ppm(path: str, rgb: np.ndarray) -> None:
+    h, w, _ = rgb.shape
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(np.ascontiguousarray(rgb, dtype=np.uint8).tobytes())
+
+
+def write_png_rgba8(path: str, rgba: np.ndarray) -> None:
+    """Minimal PNG writer (zlib + CRC from the stdlib).  The reference saves through image::save_buffer
+    (renderer.rs:67-73) as Rgba16 -- which cannot hold the CPU path's RGBA8 bytes; this
+    writes the RGBA8 pixels the CPU path actually produces."""
+    import struct
+    import zlib
+    h, w, _ = rgba.shape
+    raw = b"".join(b"\x00" + np.ascontiguousarray(rgba[y]).tobytes() for y in range(h))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
