@@ -83,8 +83,15 @@ enum MiptSeedMode {
 };
 enum MiptTraversal {
     MIPT_TRAVERSAL_REFERENCE = 0, /* cpu/ray.rs:69-81: slab test without t-max cull (the CPU backend) */
-    MIPT_TRAVERSAL_CULLED    = 1  /* rt_compute.wgsl:341-349: + `t_near < best` cull (the wgpu backend) */
+    MIPT_TRAVERSAL_CULLED    = 1  /* rt_compute.wgsl:341-349: + `t_near < best*(1+cull_margin)` cull (margin 0 = the wgpu backend's rule) */
 };
+/* Best-hit culling is not result-identical to the CPU backend at margin 0: Moller-Trumbore is not
+ * watertight, so a ray on a shared edge can hit both neighbours with distances one ulp apart, and
+ * culling the second leaf (slab t_near >= best) keeps the first-found instead of the closest
+ * (measured: ~1e-5 of rays on the 10 M-triangle scene).  A relative margin keeps every near-tie
+ * candidate in play; with 2^-7 the culled frame is bit-identical to the reference traversal on
+ * every scene tested (tests/, bench.py re-checks it on each run) at +1 % node visits. */
+#define MIPT_CULL_MARGIN_SAFE 0.0078125f
 enum MiptFlags {
     MIPT_FLAG_COUNT  = 1u << 0,   /* counting build: fill rays / inner_steps / tri_tests / ... in MiptStats */
     MIPT_FLAG_PACKED = 1u << 1,   /* tile-sharded output is rank-packed (tile-major) instead of full-frame */
@@ -101,7 +108,8 @@ typedef struct {
     uint32_t tile_rank;           /* image-tile shard: this rank ...                        */
     uint32_t tile_world;          /* ... of this many (0 or 1 = whole image); 8x8 tiles, round-robin */
     uint32_t sample_begin;        /* PER_SAMPLE: first sample number (0 -> 1, as gpu.rs:252 starts at 1) */
-    uint32_t reserved[6];         /* must be 0 */
+    float    cull_margin;         /* MIPT_TRAVERSAL_CULLED: relative margin (>= 0); see MIPT_CULL_MARGIN_SAFE */
+    uint32_t reserved[5];         /* must be 0 */
 } MiptOptions;
 
 typedef struct {
@@ -184,6 +192,13 @@ int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_de
 
 /* Material::default() (src/scene.rs:148-167). */
 void mipt_material_default(MiptMaterial *out);
+
+/* Diagnostic: evaluates one device arithmetic primitive element-wise on the GPU (host buffers in/out),
+ * so tests can pin the kernel's f32/f64 building blocks against the oracle bit for bit.
+ * op: 0 cos-shim, 1 log10-shim, 2 pow-shim(a,b), 3 a/b, 4 sqrt(a), 5 a*b, 6 a+b, 7 min, 8 max,
+ *     9 rand_f32(seed=bits(a)), 10 rand_f32_nd(seed), 11 rand_in_unit_sphere(seed)[b], 12 srgb+quantise(a)
+ *     (result as integer bits), 13 fract(a). */
+int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out);
 
 const char *mipt_last_error(void);
 int mipt_abi_version(void);

@@ -315,7 +315,8 @@ static Hit intersect_tri(const Ray *ray, const OrcTriangle *tri) { /* ray.rs:19-
 }
 
 static inline float intersect_node(const Ray *ray, const OrcNode *node, int cull, float max_distance) {
-    /* ray.rs:69-81; cull=1 adds rt_compute.wgsl:348's `t_near < max_distance` */
+    /* ray.rs:69-81; cull=1 adds rt_compute.wgsl:348's `t_near < max_distance`
+     * (the caller passes max_distance = best * (1 + cull_margin); margin 0 = the WGSL rule) */
     v3 t_min = v_div(v_sub(node->bounds_min, ray->origin), ray->direction);
     v3 t_max = v_div(v_sub(node->bounds_max, ray->origin), ray->direction);
     v3 t_1 = v_min(t_min, t_max);
@@ -326,7 +327,7 @@ static inline float intersect_node(const Ray *ray, const OrcNode *node, int cull
     return ORC_MISS;
 }
 
-typedef struct { OrcStats s; uint32_t stack_cap; int cull; int libm; } Ctx;
+typedef struct { OrcStats s; uint32_t stack_cap; int cull; float cull_scale; int libm; float *rec; uint32_t rec_cap, rec_n; uint32_t cur_tri; } Ctx;
 
 #define ORC_STACK_MAX 256
 static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx) { /* ray.rs:84-139 */
@@ -339,7 +340,7 @@ static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx)
             for (uint32_t i = 0; i < node->num_tris; i++) {
                 Hit th = intersect_tri(ray, &sc->tris[node->first_tri_or_child + i]);
                 cx->s.tri_tests++;
-                if (th.has_hit && th.distance < hit->distance) *hit = th;
+                if (th.has_hit && th.distance < hit->distance) { *hit = th; cx->cur_tri = node->first_tri_or_child + i; }
             }
             if (sp == 0) break;
             node = &sc->nodes[stack[--sp]];
@@ -347,8 +348,9 @@ static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx)
         }
         uint32_t c1 = node->first_tri_or_child, c2 = c1 + 1;
         cx->s.inner_steps++;
-        float dist_1 = intersect_node(ray, &sc->nodes[c1], cx->cull, hit->distance);
-        float dist_2 = intersect_node(ray, &sc->nodes[c2], cx->cull, hit->distance);
+        const float max_d = hit->distance * cx->cull_scale;
+        float dist_1 = intersect_node(ray, &sc->nodes[c1], cx->cull, max_d);
+        float dist_2 = intersect_node(ray, &sc->nodes[c2], cx->cull, max_d);
         if (dist_1 > dist_2) {
             float td = dist_1; dist_1 = dist_2; dist_2 = td;
             uint32_t tc = c1; c1 = c2; c2 = tc;
@@ -379,7 +381,14 @@ static v3 trace(Ray *ray, uint32_t max_bounces, const SceneView *sc, uint32_t *r
         Hit hit;
         memset(&hit, 0, sizeof hit);
         hit.distance = ORC_MISS;
+        cx->cur_tri = UINT32_MAX;
         traverse_bvh(ray, sc, &hit, cx);
+        if (cx->rec && cx->rec_n < cx->rec_cap) {     /* debug trace: o, d, tri, t (orc_debug_pixel) */
+            float *r = cx->rec + 8 * (size_t)cx->rec_n++;
+            r[0] = ray->origin.x; r[1] = ray->origin.y; r[2] = ray->origin.z;
+            r[3] = ray->direction.x; r[4] = ray->direction.y; r[5] = ray->direction.z;
+            memcpy(&r[6], &cx->cur_tri, 4); r[7] = hit.distance;
+        }
         if (hit.has_hit) {
             cx->s.hits++;
             const OrcMaterial *m = &sc->materials[hit.material_id];   /* ray.rs:153-154 */
@@ -436,7 +445,7 @@ void orc_trace_ray(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *node
                    uint32_t *rng, int cull, int libm, float out[3]) {
     SceneView sc = {tris, n_tris, nodes, n_nodes, materials, n_materials, textures, n_textures};
     Ctx cx; memset(&cx, 0, sizeof cx);
-    cx.stack_cap = 64; cx.cull = cull; cx.libm = libm;
+    cx.stack_cap = 64; cx.cull = cull; cx.cull_scale = 1.0f; cx.libm = libm;
     Ray r = {V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2])};
     v3 c = trace(&r, max_depth, &sc, rng, &cx);
     out[0] = c.x; out[1] = c.y; out[2] = c.z;
@@ -493,6 +502,7 @@ static void *worker(void *arg) {
     cx.stack_cap = job->opt.stack_cap ? job->opt.stack_cap : 64;
     if (cx.stack_cap > ORC_STACK_MAX) cx.stack_cap = ORC_STACK_MAX;
     cx.cull = (int)job->opt.cull; cx.libm = (int)job->opt.libm;
+    cx.cull_scale = 1.0f + job->opt.cull_margin;
     uint64_t stride = job->opt.pix_stride ? job->opt.pix_stride : 1;
     for (;;) {
         /* rayon's by_uniform_blocks (cpu.rs:22-26): contiguous blocks of w*h/T pixel indices */
@@ -510,6 +520,30 @@ static void *worker(void *arg) {
     if (cx.s.max_stack > job->total.max_stack) job->total.max_stack = cx.s.max_stack;
     pthread_mutex_unlock(&job->mu);
     return NULL;
+}
+
+/* Debug: render ONE pixel (all its samples, in sequence) and record every ray as 8 floats
+ * {o.xyz, d.xyz, bits(tri index or 0xffffffff), t}.  Returns the number of rays recorded. */
+uint32_t orc_debug_pixel(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+                         const OrcMaterial *materials, uint32_t n_materials,
+                         const OrcTexture *textures, uint32_t n_textures,
+                         const OrcCamera *camera, const OrcOptions *opt, uint64_t pixel_index,
+                         float *records, uint32_t rec_cap, float out_rgb[3]) {
+    Job job; memset(&job, 0, sizeof job);
+    job.sc.tris = tris; job.sc.n_tris = n_tris; job.sc.nodes = nodes; job.sc.n_nodes = n_nodes;
+    job.sc.materials = materials; job.sc.n_materials = n_materials;
+    job.sc.textures = textures; job.sc.n_textures = n_textures;
+    job.cam = camera; job.opt = *opt;
+    float *hdr = (float *)calloc((size_t)opt->width * opt->height * 3, sizeof(float));
+    job.hdr = hdr;
+    Ctx cx; memset(&cx, 0, sizeof cx);
+    cx.stack_cap = opt->stack_cap ? opt->stack_cap : 64;
+    cx.cull = (int)opt->cull; cx.libm = (int)opt->libm; cx.cull_scale = 1.0f + opt->cull_margin;
+    cx.rec = records; cx.rec_cap = rec_cap;
+    render_pixel(&job, pixel_index, &cx);
+    if (out_rgb) { out_rgb[0] = hdr[3 * pixel_index]; out_rgb[1] = hdr[3 * pixel_index + 1]; out_rgb[2] = hdr[3 * pixel_index + 2]; }
+    free(hdr);
+    return cx.rec_n;
 }
 
 int orc_render(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,

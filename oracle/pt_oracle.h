@@ -80,6 +80,7 @@ typedef struct {
     uint32_t sample_begin;           /* PER_SAMPLE mode: first sample number (>=1), 0 -> 1 */
     uint32_t stack_cap;              /* traversal stack entries; 0 -> 64 (reference: 32, ray.rs:85) */
     uint32_t sum_only;               /* 1: hdr = sum over samples (no /samples), for sample-sharding */
+    float    cull_margin;            /* cull=1: skip a child iff !(t_near < best*(1+margin)); 0 = the WGSL rule */
 } OrcOptions;
 
 typedef struct {
@@ -112,6 +113,12 @@ int orc_render(const OrcTriangle *tris, uint32_t n_tris,
                const OrcTexture *textures, uint32_t n_textures,
                const OrcCamera *camera, const OrcOptions *opt,
                float *hdr, uint8_t *rgba8, OrcStats *stats);
+
+uint32_t orc_debug_pixel(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+                         const OrcMaterial *materials, uint32_t n_materials,
+                         const OrcTexture *textures, uint32_t n_textures,
+                         const OrcCamera *camera, const OrcOptions *opt, uint64_t pixel_index,
+                         float *records, uint32_t rec_cap, float out_rgb[3]);
 
 /* ---- small entry points for the known-answer tests ---- */
 uint32_t orc_pixel_seed(uint32_t index);                        /* cpu.rs:28-29 */

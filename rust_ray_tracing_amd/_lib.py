@@ -31,6 +31,7 @@ NO_TEXTURE = 0xFFFFFFFF
 SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
 FLAG_COUNT, FLAG_PACKED, FLAG_SUM = 1, 2, 4
+CULL_MARGIN_SAFE = 0.0078125  # MIPT_CULL_MARGIN_SAFE
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_SCENE_LIMIT, ERR_BVH, ERR_IO, ERR_STACK = 0, -1, -2, -3, -4, -5, -6
 
@@ -50,7 +51,7 @@ class MiptOptions(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
                 ("max_ray_depth", C.c_uint32), ("seed_mode", C.c_uint32), ("traversal", C.c_uint32),
                 ("flags", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32),
-                ("sample_begin", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("sample_begin", C.c_uint32), ("cull_margin", C.c_float), ("reserved", C.c_uint32 * 5)]
 
 
 class MiptStats(C.Structure):
@@ -68,7 +69,7 @@ EXPORTS = [
     "mipt_scene_create", "mipt_scene_destroy", "mipt_render", "mipt_render_device",
     "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_bvh_build",
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
-    "mipt_device_count", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
+    "mipt_device_count", "mipt_debug_eval", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
 ]
 
 _lib = None
@@ -116,6 +117,8 @@ def load() -> C.CDLL:
     lib.mipt_abi_version.restype = C.c_int
     lib.mipt_device_count.argtypes = []
     lib.mipt_device_count.restype = C.c_int
+    lib.mipt_debug_eval.argtypes = [C.c_int, vp, vp, u64, vp]
+    lib.mipt_debug_eval.restype = C.c_int
     lib.mipt_obj_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.mipt_obj_load.restype = C.c_int
     lib.mipt_obj_free.argtypes = [vp]

@@ -271,6 +271,7 @@ static int validate_options(const MiptOptions *opt) {
     if (opt->tile_rank >= world) return fail(MIPT_ERR_INVALID_ARG, "tile_rank %u >= tile_world %u", opt->tile_rank, world);
     if ((opt->flags & MIPT_FLAG_SUM) && opt->seed_mode != MIPT_SEED_PER_SAMPLE && opt->sample_begin > 1)
         return fail(MIPT_ERR_INVALID_ARG, "sample_begin needs MIPT_SEED_PER_SAMPLE (the pixel stream cannot be entered mid-way)");
+    if (!(opt->cull_margin >= 0.0f) || opt->cull_margin > 1.0f) return fail(MIPT_ERR_INVALID_ARG, "cull_margin must be in [0, 1]");
     for (uint32_t r : opt->reserved)
         if (r) return fail(MIPT_ERR_INVALID_ARG, "reserved option fields must be 0");
     return MIPT_OK;
@@ -304,6 +305,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
     pr.total_work = (unsigned long long)pr.n_local_tiles * 64ull;
     pr.aspect = (float)opt->width / (float)opt->height;       // cpu.rs:34
     pr.samples_f = (float)opt->samples;                       // cpu.rs:60
+    pr.cull_scale = 1.0f + opt->cull_margin;
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) pr.cam[c * 3 + r] = camera->look_at[c][r];
     pr.cam[9] = camera->position.x; pr.cam[10] = camera->position.y; pr.cam[11] = camera->position.z;
@@ -386,6 +388,19 @@ int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height
 int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint8_t *d_rgba8, void *hip_stream) {
     if (!d_hdr_rgb || !d_rgba8 || n_pixels == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_tonemap_device: bad argument");
     HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, n_pixels, divisor, d_rgba8, (hipStream_t)hip_stream));
+    return MIPT_OK;
+}
+
+int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out) {
+    if (!a || !out || n == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_debug_eval: bad argument");
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **)&da, n * 4));
+    HIP_TRY(hipMalloc((void **)&dout, n * 4));
+    HIP_TRY(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(hipMalloc((void **)&db, n * 4)); HIP_TRY(hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice)); }
+    HIP_TRY(mipt::launch_debug_eval(op, da, db, n, dout, nullptr));
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
     return MIPT_OK;
 }
 

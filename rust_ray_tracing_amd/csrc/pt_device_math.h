@@ -2,6 +2,7 @@
 //
 // Every function is one IEEE-754 binary32 (or, in the transcendental shim, binary64)
 // operation per source operator, evaluated in the order of the reference's Rust source;
+// (note: __builtin_sqrtf is the correctly-rounded expansion; __fsqrt_rn lowers to the 1-ulp v_sqrt_f32)
 // the translation unit is built with -ffp-contract=off so hipcc never fuses a*b+c (Rust
 // does not: SURVEY.md T11).  f32 divide and sqrt are the correctly-rounded expansions
 // (-fhip-fp32-correctly-rounded-divide-sqrt), denormals are preserved.
@@ -23,7 +24,7 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                    // vec3.rs:136-144
     return mk((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
 }
-__device__ __forceinline__ float length(V3 a) { return __fsqrt_rn((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); } // vec3.rs:93-97
+__device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); } // vec3.rs:93-97
 __device__ __forceinline__ V3 normalized(V3 a) { return a / length(a); }                             // vec3.rs:105-109
 
 // math.rs:6-13
@@ -155,7 +156,7 @@ __device__ __noinline__ float shim_powf(float x, float y) {
 // math.rs:15-19 (log10, not ln: SURVEY T3)
 __device__ __forceinline__ float rand_f32_nd(uint32_t &s) {
     float theta = 6.283185f * rand_f32(s);
-    float rho = __fsqrt_rn(-2.0f * shim_log10f(rand_f32(s)));
+    float rho = __builtin_sqrtf(-2.0f * shim_log10f(rand_f32(s)));
     return rho * shim_cosf(theta);
 }
 // vec3.rs:66-68 -- x, y, z drawn in that order

@@ -44,6 +44,7 @@ struct DevParams {
     unsigned long long total_work;          // n_local_tiles * 64
     float aspect;                           // width as f32 / height as f32 (cpu.rs:34)
     float samples_f;
+    float cull_scale;                       // 1 + cull_margin
     float cam[12];                          // look_at columns 0..2 (xyz each), position
     float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
     uint32_t *ovf;                          // traversal-stack overflow area [wave][entry][lane]
@@ -65,5 +66,8 @@ hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t
                                uint32_t tile_world, float *hdr, hipStream_t stream);
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,
                           uint8_t *rgba8, hipStream_t stream);
+
+hipError_t launch_debug_eval(int op, const float *a, const float *b, unsigned long long n, float *out,
+                             hipStream_t stream);
 
 } // namespace mipt

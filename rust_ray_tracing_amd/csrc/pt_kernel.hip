@@ -260,8 +260,9 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
                 tri_cur += 1;
                 need_pop = (tri_cur == tri_end);
             } else {                                                                 // ray.rs:108-137
-                float d1 = slab<CULL>(o, d, r0, r1, best_t);
-                float d2 = slab<CULL>(o, d, r2, r3, best_t);
+                const float max_d = best_t * pr.cull_scale;
+                float d1 = slab<CULL>(o, d, r0, r1, max_d);
+                float d2 = slab<CULL>(o, d, r2, r3, max_d);
                 uint32_t a1 = __float_as_uint(r0.w), n1 = __float_as_uint(r1.w);
                 uint32_t a2 = __float_as_uint(r2.w), n2 = __float_as_uint(r3.w);
                 uint32_t w2 = 1u;
@@ -347,6 +348,39 @@ __global__ void tonemap_kernel(const float *__restrict__ hdr, unsigned long long
         if (divisor != 1.0f) { r = r / divisor; g = g / divisor; b = b / divisor; }   // cpu.rs:60
         rgba8[i] = srgb_quantize(r) | (srgb_quantize(g) << 8) | (srgb_quantize(b) << 16) | 0xff000000u;
     }
+}
+
+// ---- device-arithmetic probe (diagnostic entry mipt_debug_eval; used by the GPU known-answer tests) ----
+__global__ void debug_eval_kernel(int op, const float *__restrict__ a, const float *__restrict__ b, unsigned long long n,
+                                  float *__restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        float r = 0.0f;
+        switch (op) {
+        case 0: r = shim_cosf(x); break;
+        case 1: r = shim_log10f(x); break;
+        case 2: r = shim_powf(x, y); break;
+        case 3: r = x / y; break;
+        case 4: r = __builtin_sqrtf(x); break;
+        case 5: r = x * y; break;
+        case 6: r = x + y; break;
+        case 7: r = fminf(x, y); break;
+        case 8: r = fmaxf(x, y); break;
+        case 9: { uint32_t s = __float_as_uint(x); r = rand_f32(s); } break;             // xorshift + u32->f32 + /2^32
+        case 10: { uint32_t s = __float_as_uint(x); r = rand_f32_nd(s); } break;
+        case 11: { uint32_t s = __float_as_uint(x); V3 v = rand_in_unit_sphere(s); r = (y == 0.0f) ? v.x : (y == 1.0f ? v.y : v.z); } break;
+        case 12: r = __uint_as_float(srgb_quantize(x)); break;
+        case 13: r = x - truncf(x); break;
+        default: break;
+        }
+        out[i] = r;
+    }
+}
+
+hipError_t launch_debug_eval(int op, const float *a, const float *b, unsigned long long n, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(debug_eval_kernel, dim3(1024), dim3(256), 0, stream, op, a, b, n, out);
+    return hipGetLastError();
 }
 
 template <bool COUNT, bool CULL>

@@ -51,6 +51,7 @@ class RendererOptions:  # renderer.rs:96-116
     # MI355X-path extensions (MiptOptions)
     seed_mode: int = L.SEED_PIXEL_STREAM
     traversal: int = L.TRAVERSAL_REFERENCE
+    cull_margin: float = L.CULL_MARGIN_SAFE
     device_id: int = 0
 
 
@@ -178,11 +179,12 @@ class Scene:  # scene.rs:12-19
 
 
 def make_options(width, height, samples, max_ray_depth, seed_mode=L.SEED_PIXEL_STREAM, traversal=L.TRAVERSAL_REFERENCE,
-                 flags=0, tile_rank=0, tile_world=0, sample_begin=0) -> L.MiptOptions:
+                 flags=0, tile_rank=0, tile_world=0, sample_begin=0, cull_margin=L.CULL_MARGIN_SAFE) -> L.MiptOptions:
     o = L.MiptOptions()
     o.width, o.height, o.samples, o.max_ray_depth = width, height, samples, max_ray_depth
     o.seed_mode, o.traversal, o.flags = seed_mode, traversal, flags
     o.tile_rank, o.tile_world, o.sample_begin = tile_rank, tile_world, sample_begin
+    o.cull_margin = cull_margin
     return o
 
 
@@ -219,7 +221,7 @@ class Renderer:  # renderer.rs:8-85
             raise NotImplementedError(f"backend {o.backend.name} is not part of this build; use RendererBackend.MI355X")
         w, h = o.output_image_dimensions
         handle = scene.upload(o.device_id)
-        opt = make_options(w, h, o.samples, o.max_ray_depth, o.seed_mode, o.traversal, flags)
+        opt = make_options(w, h, o.samples, o.max_ray_depth, o.seed_mode, o.traversal, flags, cull_margin=o.cull_margin)
         hdr = np.zeros((h, w, 3), dtype=np.float32) if want_hdr else None
         rgba = np.zeros((h, w, 4), dtype=np.uint8) if want_rgba8 else None
         st = L.MiptStats()

@@ -23,15 +23,15 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("traversal", [0, 1])
+@pytest.mark.parametrize("traversal,margin", [(0, 0.0), (1, 0.0), (1, 0.0078125)])
 @pytest.mark.parametrize("kind,kw,w,h,spp,depth", CASES)
-def test_hdr_bit_exact(rrt, orc, kind, kw, w, h, spp, depth, traversal):
+def test_hdr_bit_exact(rrt, orc, kind, kw, w, h, spp, depth, traversal, margin):
     sc = _scene(rrt, kind, **kw)
     r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h),
-                                             output_image_path="/dev/null", traversal=traversal))
+                                             output_image_path="/dev/null", traversal=traversal, cull_margin=margin))
     hdr, rgba, st = r.render_buffers(sc, flags=rrt.FLAG_COUNT)
     ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform,
-                                    w, h, spp, depth, cull=traversal)
+                                    w, h, spp, depth, cull=traversal, cull_margin=margin)
     assert st["pixels"] == w * h
     for k in ("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "max_stack"):
         assert st[k] == rst[k], k

@@ -1,0 +1,35 @@
+"""GPU box: full-size frame, GPU culled / GPU reference / oracle culled / oracle reference on a strided sample."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rust_ray_tracing_amd as rrt
+from rust_ray_tracing_amd import synth
+from oracle import orc
+n_tris = int(sys.argv[1]); w, h, spp, depth, stride = map(int, sys.argv[2:7])
+tris, mats, texs, cam = synth.atrium_scene(n_target=n_tris, tex_size=256)
+sc = rrt.Scene.from_arrays(tris, mats, texs)
+sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+out = {}
+MARGIN = float(sys.argv[7]) if len(sys.argv) > 7 else 0.0078125
+for trav in (0, 1):
+    r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h), output_image_path="/dev/null", traversal=trav, cull_margin=MARGIN))
+    hdr, _, st = r.render_buffers(sc, want_rgba8=False, flags=rrt.FLAG_COUNT)
+    print("gpu trav", trav, st)
+    out[("gpu", trav)] = hdr.reshape(-1, 3)
+    ref, _, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, w, h, spp, depth, cull=trav, cull_margin=MARGIN, pix_stride=stride, want_rgba8=False)
+    print("cpu trav", trav, rst)
+    out[("cpu", trav)] = ref.reshape(-1, 3)
+idx = np.arange(0, w * h, stride)
+def cmp(a, b, sel=None):
+    x = out[a].view(np.uint32); y = out[b].view(np.uint32)
+    if sel is not None: x = x[sel]; y = y[sel]
+    d = (x != y).any(axis=1)
+    return int(d.sum()), len(d)
+print("gpu0 vs gpu1 (all pixels):", cmp(("gpu", 0), ("gpu", 1)))
+print("gpu0 vs cpu0 (sample):", cmp(("gpu", 0), ("cpu", 0), idx))
+print("gpu1 vs cpu1 (sample):", cmp(("gpu", 1), ("cpu", 1), idx))
+print("cpu0 vs cpu1 (sample):", cmp(("cpu", 0), ("cpu", 1), idx))
+x = out[("gpu", 0)][idx]; y = out[("cpu", 0)][idx]
+bad = np.nonzero((x.view(np.uint32) != y.view(np.uint32)).any(axis=1))[0]
+for b in bad[:8]:
+    print("  pixel", idx[b], x[b], y[b])
