@@ -1,0 +1,286 @@
+"""-m gpu: goldens, edge cases, device-arithmetic known answers, shards and full-size properties of the HIP path
+(all through the C ABI)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def _scene(rrt, kind, **kw):
+    from rust_ray_tracing_amd import synth
+    tris, mats, texs, cam = synth.make_scene(kind, **kw)
+    sc = rrt.Scene.from_arrays(tris, mats, texs)
+    sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    return sc
+
+
+def _render(rrt, sc, w, h, spp, depth, **kw):
+    flags = kw.pop("flags", rrt.FLAG_COUNT)
+    r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h),
+                                             output_image_path="/dev/null", **kw))
+    return r.render_buffers(sc, flags=flags)
+
+
+def _raw(rrt, sc, opt, n_floats):
+    """mipt_render with explicit MiptOptions into a host buffer of n_floats."""
+    from rust_ray_tracing_amd import _lib as L
+    out = np.zeros(n_floats, dtype=np.float32)
+    st = L.MiptStats()
+    L.check(rrt.load().mipt_render(sc.upload(0), L.ptr(sc.camera.uniform), C.byref(opt), L.ptr(out), None, C.byref(st)), "mipt_render")
+    return out, st.as_dict()
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cornell_64x64_4spp", "helmet4k_96x54_4spp", "atrium20k_64x36_2spp",
+                                  "atrium20k_64x36_4spp_persample", "cornell_256x256_4spp_rgba"])
+def test_against_committed_goldens(rrt, name):
+    import make_golden
+    kind, kw, w, h, spp, depth, seed_mode = make_golden.CASES[name]
+    sc = _scene(rrt, kind, **kw)
+    hdr, rgba, st = _render(rrt, sc, w, h, spp, depth, seed_mode=seed_mode)
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    assert st["rays"] == int(g["rays"])
+    assert np.array_equal(rgba, g["rgba"])
+    if "hdr" in g:
+        assert np.array_equal(hdr.view(np.uint32), g["hdr"].view(np.uint32))
+        assert st["inner_steps"] == int(g["inner_steps"]) and st["tri_tests"] == int(g["tri_tests"])
+
+
+def test_config1_obj_to_pixels(rrt, orc, tmp_path):
+    """BASELINE.json configs[0]: 12-triangle OBJ, 256x256, 4 spp -- OBJ -> Scene -> BVH -> render, vs the oracle."""
+    from rust_ray_tracing_amd import synth
+    sc = rrt.Scene.load(synth.write_cornell_obj(str(tmp_path)))
+    sc.set_camera(rrt.Camera(position=synth.CORNELL_CAMERA[0], pitch=0.0, yaw=0.0))
+    hdr, rgba, st = _render(rrt, sc, 256, 256, 4, 64)
+    ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), [], sc.camera.uniform, 256, 256, 4, 64)
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgba, ref_rgba)
+    assert rgba[0, 0].tolist() == [254, 254, 254, 255]          # white sky quantises to 254 in f32 (test_oracle_kat)
+    raw = rrt.Renderer.new(rrt.RendererOptions(samples=4, max_ray_depth=64, output_image_dimensions=(256, 256),
+                                               output_image_path=str(tmp_path / "out.png"))).render(sc)
+    assert raw == ref_rgba.tobytes() and len(raw) == 256 * 256 * 4   # the Vec<u8> cpu.rs:63-67 returns
+    assert (tmp_path / "out.png").stat().st_size > 100
+
+
+# ---- edge cases the reference's structure implies -----------------------------------------------------
+def test_root_leaf_single_triangle_and_one_pixel(rrt, orc):
+    from rust_ray_tracing_amd import TRIANGLE
+    t = np.zeros(1, dtype=TRIANGLE)
+    t["vertices"]["position"][0] = [(-5, -5, -5), (-5, 5, 5), (-5, 5, -5)]
+    t["vertices"]["normal"][0] = [(1, 0, 0)] * 3
+    sc = rrt.Scene.from_arrays(t, [rrt.material_default()])
+    assert len(sc.bvh_nodes) == 1
+    sc.set_camera(rrt.Camera(position=(3, 0, 0), pitch=0.0, yaw=0.0))
+    for (w, h, spp) in [(1, 1, 1), (5, 3, 7), (64, 64, 2)]:
+        hdr, rgba, st = _render(rrt, sc, w, h, spp, 4)
+        ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), [], sc.camera.uniform, w, h, spp, 4)
+        assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgba, ref_rgba)
+        assert st["rays"] == rst["rays"] and st["pixels"] == w * h
+
+
+def test_big_leaves_and_deep_stack(rrt, orc):
+    """>= 64 triangles in one leaf (child-ref stack entries) and a stack deeper than the 16 LDS entries (HBM spill)."""
+    from rust_ray_tracing_amd import TRIANGLE
+    n = 150                                             # identical AABBs -> identical centroids -> unsplittable leaf
+    big = np.zeros(n, dtype=TRIANGLE)
+    tt = np.linspace(-0.95, 0.95, n).astype(np.float32)
+    for i in range(n):                                  # coplanar, overlapping: equal-t hits exercise the strict-< order (T6)
+        big["vertices"]["position"][i] = [(-4.0, -1.0, -1.0), (-4.0, 1.0, 1.0), (-4.0, tt[i], -tt[i])]
+    big["vertices"]["normal"] = (1, 0, 0)
+    # a long chain of ever larger nested shells in front forces many pending far children
+    from rust_ray_tracing_amd import synth
+    shells = []
+    for k in range(40):
+        r = 0.2 * 1.25 ** k
+        q = synth.quad((-2 - 0.02 * k, -r, -r), (-2 - 0.02 * k, r, -r), (-2 - 0.02 * k, r, r), (-2 - 0.02 * k, -r, r), (1, 0, 0), 0)
+        shells.append(q)
+    tris = np.concatenate([big] + shells)
+    sc = rrt.Scene.from_arrays(tris, [rrt.material_default()])
+    assert sc.bvh_nodes["num_tris"].max() >= 64
+    sc.set_camera(rrt.Camera(position=(3, 0.01, 0.02), pitch=0.0, yaw=0.0))
+    hdr, rgba, st = _render(rrt, sc, 96, 96, 2, 6)
+    ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), [], sc.camera.uniform, 96, 96, 2, 6)
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
+    assert st["max_stack"] == rst["max_stack"] and st["tri_tests"] == rst["tri_tests"]
+    # and a genuinely deep traversal stack: the 1M-triangle atrium needs > 16 entries on some rays
+    sc = _scene(rrt, "atrium", n_target=1_000_000, tex_size=64)
+    hdr, _, st = _render(rrt, sc, 256, 144, 2, 32)
+    ref, _, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, 256, 144, 2, 32, want_rgba8=False)
+    assert st["max_stack"] == rst["max_stack"]
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
+
+
+def test_stack_overflow_is_reported_not_hidden(rrt):
+    """The reference panics when its 32-entry stack overflows (ray.rs:85); the kernel has 64 entries and
+    returns MIPT_ERR_STACK beyond that.  A normal scene must report zero overflows."""
+    sc = _scene(rrt, "dragon", n_target=30000)
+    _, _, st = _render(rrt, sc, 64, 36, 1, 8)
+    assert st["stack_overflows"] == 0 and st["tex_clamped"] == 0
+
+
+def test_option_validation_on_device(rrt):
+    from rust_ray_tracing_amd import _lib as L
+    sc = _scene(rrt, "cornell")
+    lib = rrt.load()
+    h = sc.upload(0)
+    buf = np.zeros(64 * 64 * 3, dtype=np.float32)
+    for bad in (dict(width=0), dict(samples=0), dict(max_ray_depth=0), dict(seed_mode=7), dict(traversal=9), dict(tile_rank=2, tile_world=2)):
+        o = rrt.make_options(64, 64, 1, 4)
+        for k, v in bad.items():
+            setattr(o, k, v)
+        assert lib.mipt_render(h, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, None) == L.ERR_INVALID_ARG, bad
+    o = rrt.make_options(46341, 46341, 1, 1)            # w*h >= 2^31 - 87636354: 32-bit pixel seed would wrap
+    assert lib.mipt_render(h, L.ptr(sc.camera.uniform), C.byref(o), None, None, None) == L.ERR_INVALID_ARG
+
+
+# ---- the kernel's arithmetic building blocks, bit for bit ----------------------------------------------
+def test_device_arithmetic_matches_oracle(rrt, orc):
+    lib, O = rrt.load(), orc.load()
+
+    def dev(op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.zeros_like(a)
+        bb = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+        assert lib.mipt_debug_eval(op, a.ctypes.data, None if bb is None else bb.ctypes.data, a.size, out.ctypes.data) == 0
+        return out
+
+    def same(x, y):
+        return np.all((x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y)))
+    rng = np.random.default_rng(1)
+    n = 400_000
+    a = (rng.standard_normal(n) * np.exp(rng.uniform(-40, 40, n))).astype(np.float32)
+    b = (rng.standard_normal(n) * np.exp(rng.uniform(-40, 40, n))).astype(np.float32)
+    a[:8] = [0, -0.0, np.inf, -np.inf, np.nan, 1, 1e-45, 3e38]
+    b[:8] = [0, 1, np.inf, 0, 1, 0, 3, 1e-45]
+    with np.errstate(all="ignore"):
+        assert same(dev(3, a, b), a / b)                       # IEEE division (slab test, normalize)
+        assert same(dev(4, np.abs(a)), np.sqrt(np.abs(a)))     # correctly rounded sqrt (vec3.rs:95)
+        assert same(dev(5, a, b), a * b) and same(dev(6, a, b), a + b)   # denormals preserved, no FMA
+    x = np.concatenate([(rng.random(50000) * 6.2832).astype(np.float32), np.float32([0, 6.283185, 3.1415927, 1.5707964, np.inf, np.nan])])
+    assert same(dev(0, x), np.array([O.orc_shim_cosf(float(v)) for v in x], dtype=np.float32))
+    r = np.concatenate([rng.random(50000).astype(np.float32), np.float32([0, 1, 1e-45, 2.3e-10, np.inf, -1])])
+    assert same(dev(1, r), np.array([O.orc_shim_log10f(float(v)) for v in r], dtype=np.float32))
+    y = np.full(len(r), np.float32(1) / np.float32(2.4), dtype=np.float32)
+    assert same(dev(2, r, y), np.array([O.orc_shim_powf(float(v), float(y[0])) for v in r], dtype=np.float32))
+    seeds = rng.integers(1, 2**32, 30000, dtype=np.uint32)
+    want = np.zeros((len(seeds), 3), dtype=np.float32)
+    for i, sd in enumerate(seeds):
+        st = C.c_uint32(int(sd))
+        o3 = (C.c_float * 3)()
+        O.orc_rand_in_unit_sphere(C.byref(st), 0, C.byref(o3))
+        want[i] = list(o3)
+    for comp in range(3):
+        assert same(dev(11, seeds.view(np.float32), np.full(len(seeds), comp, np.float32)), want[:, comp])
+    # sRGB + quantise epilogue
+    v = np.concatenate([rng.random(20000).astype(np.float32) * 1.2, np.float32([0, 1, 0.0031308, 7.5, np.nan, -0.5])])
+    got = dev(12, v).view(np.uint32)
+    for i in range(len(v)):
+        s3 = (C.c_float * 3)()
+        q3 = (C.c_uint8 * 3)()
+        O.orc_linear_to_srgb(C.byref((C.c_float * 3)(v[i], v[i], v[i])), 0, C.byref(s3))
+        O.orc_quantize(C.byref(s3), C.byref(q3))
+        assert got[i] == q3[0], (v[i], got[i], q3[0])
+
+
+# ---- shards (multi-GPU path on one GPU: loop the virtual ranks) --------------------------------------
+@pytest.mark.parametrize("w,h,world", [(64, 40, 2), (61, 37, 3), (128, 72, 8)])
+def test_tile_shards_reassemble_bit_exact(rrt, w, h, world):
+    import torch
+    from rust_ray_tracing_amd import _lib as L
+    from rust_ray_tracing_amd import sharding
+    lib = rrt.load()
+    sc = _scene(rrt, "atrium", n_target=20000, tex_size=32)
+    full, _ = _raw(rrt, sc, rrt.make_options(w, h, 2, 8), w * h * 3)
+    slots = int(lib.mipt_packed_pixels(w, h, world))
+    assert slots == sharding.packed_pixels(w, h, world)
+    packed_all = np.zeros((world, slots, 3), dtype=np.float32)
+    total_px = 0
+    for r in range(world):
+        out, st = _raw(rrt, sc, rrt.make_options(w, h, 2, 8, flags=L.FLAG_PACKED, tile_rank=r, tile_world=world), slots * 3)
+        packed_all[r] = out.reshape(slots, 3)
+        total_px += st["pixels"]
+        pix = sharding.slot_pixels(w, h, r, world)                 # kernel and Python agree on the slot layout
+        assert np.array_equal(out.reshape(slots, 3)[pix >= 0].view(np.uint32), full.reshape(-1, 3)[pix[pix >= 0]].view(np.uint32))
+    assert total_px == w * h
+    # device-side de-interleave of the all-gathered slices (what bench.py runs after the RCCL all-gather)
+    d_all = torch.from_numpy(packed_all.reshape(-1)).cuda()
+    d_frame = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    L.check(lib.mipt_unpack_tiles(C.c_void_p(d_all.data_ptr()), w, h, world, C.c_void_p(d_frame.data_ptr()),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mipt_unpack_tiles")
+    torch.cuda.synchronize()
+    assert np.array_equal(d_frame.cpu().numpy().view(np.uint32), full.view(np.uint32))
+    assert np.array_equal(sharding.unpack(packed_all, w, h, world).reshape(-1).view(np.uint32), full.view(np.uint32))
+    # full-frame (non-packed) shard output writes only the rank's pixels
+    part, st = _raw(rrt, sc, rrt.make_options(w, h, 2, 8, tile_rank=1, tile_world=world), w * h * 3)
+    own = sharding.slot_pixels(w, h, 1, world)
+    own = own[own >= 0]
+    assert np.array_equal(part.reshape(-1, 3)[own].view(np.uint32), full.reshape(-1, 3)[own].view(np.uint32))
+    mask = np.ones(w * h, bool)
+    mask[own] = False
+    assert np.all(part.reshape(-1, 3)[mask] == 0)
+
+
+def test_sample_shards_per_sample_seeds(rrt, orc):
+    """Config 5: disjoint sample ranges with the per-sample seed (rt_compute.wgsl:102), un-normalised sums."""
+    from rust_ray_tracing_amd import _lib as L
+    from rust_ray_tracing_amd import sharding
+    sc = _scene(rrt, "atrium", n_target=20000, tex_size=32)
+    w, h, spp, depth, world = 64, 36, 7, 8, 3
+    m = sc.materials_array()
+    total = np.zeros(w * h * 3, dtype=np.float32)
+    for (s0, n) in sharding.sample_ranges(spp, world):
+        part, st = _raw(rrt, sc, rrt.make_options(w, h, n, depth, seed_mode=L.SEED_PER_SAMPLE, flags=L.FLAG_SUM, sample_begin=s0), w * h * 3)
+        ref, _, _ = orc.render(sc.tris, sc.bvh_nodes, m, sc.textures, sc.camera.uniform, w, h, n, depth, seed_mode=1,
+                               sample_begin=s0, sum_only=1, want_rgba8=False)
+        assert np.array_equal(part.view(np.uint32), ref.reshape(-1).view(np.uint32))   # per-rank partial: bit-exact
+        total += part
+    whole, _, _ = orc.render(sc.tris, sc.bvh_nodes, m, sc.textures, sc.camera.uniform, w, h, spp, depth, seed_mode=1, sum_only=1, want_rgba8=False)
+    assert np.allclose(total, whole.reshape(-1), rtol=1e-6, atol=1e-6)                   # rank-tree vs sequential f32 sum
+
+
+def test_tonemap_device_matches_render_path(rrt):
+    import torch
+    from rust_ray_tracing_amd import _lib as L
+    sc = _scene(rrt, "helmet", n_target=4000, tex_size=64)
+    hdr, rgba, _ = _render(rrt, sc, 96, 54, 4, 12)
+    d = torch.from_numpy(hdr.reshape(-1) * np.float32(4)).cuda()
+    out = torch.zeros(96 * 54 * 4, dtype=torch.uint8, device="cuda")
+    L.check(rrt.load().mipt_tonemap_device(C.c_void_p(d.data_ptr()), 96 * 54, 4.0, C.c_void_p(out.data_ptr()), None), "tonemap")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(54, 96, 4)
+    assert np.mean(got != rgba) < 0.01            # (x*4)/4 == x except at f32 overflow/denormal edges
+    assert np.array_equal(got[..., 3], rgba[..., 3])
+
+
+# ---- BASELINE.json's full sizes: size-independent properties --------------------------------------------
+def test_full_size_properties_config_M(rrt, orc):
+    """1920x1080, 8 spp, depth 64 on a 2M-triangle atrium: (i) culled traversal with the safe margin is bit-identical
+    to the reference traversal over the WHOLE frame; (ii) a strided sample equals the oracle bit for bit;
+    (iii) rendering twice is idempotent; (iv) checksums of the tile shards add up to the frame's."""
+    from rust_ray_tracing_amd import _lib as L
+    sc = _scene(rrt, "atrium", n_target=2_000_000, tex_size=256)
+    w, h, spp, depth = 1920, 1080, 8, 64
+    ref_t, st0 = _raw(rrt, sc, rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_REFERENCE, flags=L.FLAG_COUNT), w * h * 3)
+    cul, st1 = _raw(rrt, sc, rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_CULLED, flags=L.FLAG_COUNT), w * h * 3)
+    assert st0["rays"] == st1["rays"] and st0["hits"] == st1["hits"] and st1["inner_steps"] < st0["inner_steps"]
+    assert np.array_equal(ref_t.view(np.uint32), cul.view(np.uint32))
+    again, _ = _raw(rrt, sc, rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_CULLED), w * h * 3)
+    assert np.array_equal(again.view(np.uint32), cul.view(np.uint32))
+    stride = 997
+    o, _, ost = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, w, h, spp, depth,
+                           pix_stride=stride, want_rgba8=False)
+    idx = np.arange(0, w * h, stride)
+    assert np.array_equal(o.reshape(-1, 3)[idx].view(np.uint32), cul.reshape(-1, 3)[idx].view(np.uint32))
+    csum = int(cul.view(np.uint32).astype(np.uint64).sum())
+    parts = 0
+    for r in range(4):
+        p, st = _raw(rrt, sc, rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_CULLED, flags=L.FLAG_PACKED, tile_rank=r, tile_world=4),
+                     int(rrt.load().mipt_packed_pixels(w, h, 4)) * 3)
+        parts += int(p.view(np.uint32).astype(np.uint64).sum())
+    assert parts == csum                                         # 1080p has no ragged tiles: padding slots stay 0
+    assert float(np.isfinite(cul).mean()) == 1.0 and 0.01 < float(cul.mean()) < 5.0
