@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N>1 code path on fewer GPUs than ranks (collectives staged through host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,10 +76,24 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X backend has no CPU fallback")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    on_host = args.dist_backend == "gloo"
+
+    def all_reduce_(t, op=dist.ReduceOp.SUM):
+        if on_host:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
     lib = rrt.load()
 
     # ---- scene (identical on every rank: seeded generator + deterministic builder) ----
@@ -116,8 +132,13 @@ def main():
 
     def step():
         st = render()
-        if packed:
+        if packed and on_host:
+            c_all = torch.empty(d_all.shape, dtype=d_all.dtype)
+            dist.all_gather_into_tensor(c_all, d_local.cpu())
+            d_all.copy_(c_all)
+        elif packed:
             dist.all_gather_into_tensor(d_all, d_local)
+        if packed:
             L.check(lib.mipt_unpack_tiles(C.c_void_p(d_all.data_ptr()), w, h, world, C.c_void_p(d_frame.data_ptr()),
                                           C.c_void_p(stream.cuda_stream)), "mipt_unpack_tiles")
         return st
@@ -128,7 +149,7 @@ def main():
                           dtype=torch.int64, device=dev)
     local_counts = {k: int(v) for k, v in zip(("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels"), counts.tolist())}
     if world > 1:
-        dist.all_reduce(counts)
+        all_reduce_(counts)
     tot = {k: int(v) for k, v in zip(("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels"), counts.tolist())}
     assert tot["pixels"] == n_pix, (tot["pixels"], n_pix)
     log(rank, f"counts: {tot}")
@@ -148,7 +169,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        all_reduce_(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
     value = tot["rays"] * args.steps / elapsed / 1e6

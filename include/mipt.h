@@ -123,7 +123,11 @@ typedef struct {
     uint64_t tex_clamped;         /* texel index clamped (reference panics, texture.rs:37) */
     uint64_t max_stack;           /* deepest stack occupancy [COUNT] */
     uint64_t pixels;              /* pixels this call produced */
-    uint64_t reserved[6];
+    /* wave-occupancy diagnostics [COUNT]: traversal iterations (per wave); sum of lanes on an inner step; sum of lanes on
+     * a leaf step; iterations that executed the inner branch; the leaf branch; service passes; lanes serviced;
+     * wave-cycles inside service passes; wave-cycles alive; wave-cycles waiting for the traversal loads (only in a
+     * -DMIPT_DIAG_STAMPS=1 build) */
+    uint64_t diag[10];
 } MiptStats;
 
 enum MiptStatus {
@@ -197,7 +201,7 @@ void mipt_material_default(MiptMaterial *out);
  * so tests can pin the kernel's f32/f64 building blocks against the oracle bit for bit.
  * op: 0 cos-shim, 1 log10-shim, 2 pow-shim(a,b), 3 a/b, 4 sqrt(a), 5 a*b, 6 a+b, 7 min, 8 max,
  *     9 rand_f32(seed=bits(a)), 10 rand_f32_nd(seed), 11 rand_in_unit_sphere(seed)[b], 12 srgb+quantise(a)
- *     (result as integer bits), 13 fract(a). */
+ *     (result as integer bits), 13 fract(a), 14 the per-ray-reciprocal division a/b (valid on its checked range). */
 int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out);
 
 const char *mipt_last_error(void);

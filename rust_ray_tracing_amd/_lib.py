@@ -58,10 +58,12 @@ class MiptStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("rays", C.c_uint64), ("inner_steps", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("texel_fetches", C.c_uint64),
                 ("stack_overflows", C.c_uint64), ("tex_clamped", C.c_uint64), ("max_stack", C.c_uint64),
-                ("pixels", C.c_uint64), ("reserved", C.c_uint64 * 6)]
+                ("pixels", C.c_uint64), ("diag", C.c_uint64 * 10)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "diag"}
+        d["diag"] = list(self.diag)
+        return d
 
 
 # every symbol include/mipt.h declares (tests/test_abi.py checks the list against the header)

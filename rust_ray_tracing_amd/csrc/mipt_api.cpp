@@ -344,6 +344,9 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
         stats->rays = hs.rays; stats->inner_steps = hs.inner_steps; stats->tri_tests = hs.tri_tests;
         stats->hits = hs.hits; stats->texel_fetches = hs.texel_fetches; stats->stack_overflows = hs.stack_overflows;
         stats->tex_clamped = hs.tex_clamped; stats->max_stack = hs.max_stack; stats->pixels = hs.pixels;
+        stats->diag[0] = hs.d_iters; stats->diag[1] = hs.d_inner_lanes; stats->diag[2] = hs.d_leaf_lanes;
+        stats->diag[3] = hs.d_iters_inner; stats->diag[4] = hs.d_iters_leaf; stats->diag[5] = hs.d_services;
+        stats->diag[6] = hs.d_service_lanes; stats->diag[7] = hs.d_cycles_service; stats->diag[8] = hs.d_cycles_total; stats->diag[9] = hs.d_cycles_mem;
     }
     if (hs.stack_overflows)
         return fail(MIPT_ERR_STACK, "traversal stack overflowed %llu times (capacity %d; the reference panics at 32, ray.rs:85)",

@@ -34,6 +34,10 @@ struct DevStats {                 // zeroed before every launch
     unsigned long long queue;     // next work index
     unsigned long long rays, inner_steps, tri_tests, hits, texel_fetches;
     unsigned long long stack_overflows, tex_clamped, max_stack, pixels;
+    // wave-level occupancy diagnostics (COUNT build): traversal iterations, lanes doing inner / leaf work,
+    // iterations that ran the inner / leaf branch, service passes, lanes serviced
+    unsigned long long d_iters, d_inner_lanes, d_leaf_lanes, d_iters_inner, d_iters_leaf, d_services, d_service_lanes;
+    unsigned long long d_cycles_service, d_cycles_total, d_cycles_mem;   // per-wave s_memtime cycles spent in service passes / alive
 };
 
 struct DevParams {

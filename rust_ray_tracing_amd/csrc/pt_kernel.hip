@@ -19,6 +19,10 @@ namespace mipt {
 
 namespace {
 
+#ifndef MIPT_DIAG_STAMPS
+#define MIPT_DIAG_STAMPS 0
+#endif
+constexpr bool DIAG_STAMPS = MIPT_DIAG_STAMPS != 0;   // counting build only: in-iteration s_memtime stamps
 constexpr float kMiss = 1e30f;                     // ray.rs:79,217
 constexpr uint32_t kNoTri = 0xffffffffu;
 constexpr uint32_t kFrontBit = 0x80000000u;
@@ -45,11 +49,31 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// ray.rs:69-81 (+ rt_compute.wgsl:348's t_near < max_distance when CULL)
+// ---- exact division with a per-ray reciprocal -------------------------------------------------------------
+// The slab test divides by the ray direction 12 times per inner step (ray.rs:70-71) and bit-exactness forbids
+// `x * (1/d)`.  hipcc's IEEE expansion is 11 instructions per quotient (2 div_scale, rcp, 2 reciprocal-refinement
+// FMAs, mul, 3 residual FMAs, div_fmas, div_fixup).  Everything that depends only on d is hoisted to once per ray:
+// r = RN(1/d); per quotient the same quotient refinement the hardware sequence ends with remains --
+//   q0 = a*r; q1 = q0 + (a - q0*d)*r; q2 = q1 + (a - q1*d)*r      (residuals exact in FMA)
+// q1 is faithful, q2 = RN(a/d) (Markstein's theorem) -- PROVIDED nothing under/overflows.  That is guaranteed when
+// |d| in [2^-60, 2] (checked once per ray) and |q| in (2^-40, 2^100) (checked on the results, see slab_pair):
+// then |a| >= 2^-100, so every residual is representable.  Lanes failing the check (a == 0: origin exactly on a
+// bounding plane; axis-parallel rays; inf/NaN) redo the step with IEEE divisions.  The probe op 14 and
+// tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
+__device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
+    const float q0 = a * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
+}
+__device__ __forceinline__ bool ray_dir_safe(V3 d) {
+    const float lo = 8.6736174e-19f /* 2^-60 */, hi = 2.0f;
+    return (fabsf(d.x) >= lo) && (fabsf(d.x) <= hi) && (fabsf(d.y) >= lo) && (fabsf(d.y) <= hi) &&
+           (fabsf(d.z) >= lo) && (fabsf(d.z) <= hi);
+}
+
+// ray.rs:69-81 on quotients already computed (+ rt_compute.wgsl:348's t_near < max_distance when CULL)
 template <bool CULL>
-__device__ __forceinline__ float slab(V3 o, V3 d, float4 lo, float4 hi, float best) {
-    float tminx = (lo.x - o.x) / d.x, tminy = (lo.y - o.y) / d.y, tminz = (lo.z - o.z) / d.z;
-    float tmaxx = (hi.x - o.x) / d.x, tmaxy = (hi.y - o.y) / d.y, tmaxz = (hi.z - o.z) / d.z;
+__device__ __forceinline__ float slab_from_t(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz, float best) {
     float t1x = fminf(tminx, tmaxx), t1y = fminf(tminy, tmaxy), t1z = fminf(tminz, tmaxz);
     float t2x = fmaxf(tminx, tmaxx), t2y = fmaxf(tminy, tmaxy), t2z = fmaxf(tminz, tmaxz);
     float t_near = fmaxf(fmaxf(t1x, t1y), t1z);
@@ -57,6 +81,38 @@ __device__ __forceinline__ float slab(V3 o, V3 d, float4 lo, float4 hi, float be
     bool ok = (t_near <= t_far) && (t_far > 0.0f);
     if (CULL) ok = ok && (t_near < best);
     return ok ? t_near : kMiss;
+}
+template <bool CULL>
+__device__ __forceinline__ float slab(V3 o, V3 d, float4 lo, float4 hi, float best) {
+    return slab_from_t<CULL>((lo.x - o.x) / d.x, (lo.y - o.y) / d.y, (lo.z - o.z) / d.z,
+                             (hi.x - o.x) / d.x, (hi.y - o.y) / d.y, (hi.z - o.z) / d.z, best);
+}
+// both children of a pair; fast quotients when `safe`, IEEE divisions for the lanes where the range check fails
+template <bool CULL>
+__device__ __forceinline__ void slab_pair(V3 o, V3 d, V3 rd, bool safe, float4 r0, float4 r1, float4 r2, float4 r3,
+                                          float best, float &d1, float &d2) {
+    const float a0 = r0.x - o.x, a1 = r0.y - o.y, a2 = r0.z - o.z, a3 = r1.x - o.x, a4 = r1.y - o.y, a5 = r1.z - o.z;
+    const float b0 = r2.x - o.x, b1 = r2.y - o.y, b2 = r2.z - o.z, b3 = r3.x - o.x, b4 = r3.y - o.y, b5 = r3.z - o.z;
+    const float p0 = fdiv_ray(a0, d.x, rd.x), p1 = fdiv_ray(a1, d.y, rd.y), p2 = fdiv_ray(a2, d.z, rd.z);
+    const float p3 = fdiv_ray(a3, d.x, rd.x), p4 = fdiv_ray(a4, d.y, rd.y), p5 = fdiv_ray(a5, d.z, rd.z);
+    const float q0 = fdiv_ray(b0, d.x, rd.x), q1 = fdiv_ray(b1, d.y, rd.y), q2 = fdiv_ray(b2, d.z, rd.z);
+    const float q3 = fdiv_ray(b3, d.x, rd.x), q4 = fdiv_ray(b4, d.y, rd.y), q5 = fdiv_ray(b5, d.z, rd.z);
+    const float mn = fminf(fminf(fminf(fabsf(p0), fabsf(p1)), fminf(fabsf(p2), fabsf(p3))),
+                           fminf(fminf(fminf(fabsf(p4), fabsf(p5)), fminf(fabsf(q0), fabsf(q1))),
+                                 fminf(fminf(fabsf(q2), fabsf(q3)), fminf(fabsf(q4), fabsf(q5)))));
+    const float mx = fmaxf(fmaxf(fmaxf(fabsf(p0), fabsf(p1)), fmaxf(fabsf(p2), fabsf(p3))),
+                           fmaxf(fmaxf(fmaxf(fabsf(p4), fabsf(p5)), fmaxf(fabsf(q0), fabsf(q1))),
+                                 fmaxf(fmaxf(fabsf(q2), fabsf(q3)), fmaxf(fabsf(q4), fabsf(q5)))));
+    // NaN quotients are dropped by fmin/fmax, so test them through the sum as well
+    const float chk = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (q0 + q1)) + ((q2 + q3) + (q4 + q5));
+    const bool ok = safe && (mn > 9.094947e-13f /* 2^-40 */) && (mx < 1.2676506e30f /* 2^100 */) && (chk == chk);
+    if (ok) {
+        d1 = slab_from_t<CULL>(p0, p1, p2, p3, p4, p5, best);
+        d2 = slab_from_t<CULL>(q0, q1, q2, q3, q4, q5, best);
+    } else {
+        d1 = slab<CULL>(o, d, r0, r1, best);
+        d2 = slab<CULL>(o, d, r2, r3, best);
+    }
 }
 
 // texture.rs:33-38; out-of-range indices (reference: panic) are clamped and counted
@@ -90,7 +146,8 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
 
     // ---- per-lane path state ----
     uint32_t state = ST_P;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), rd = mk(0, 0, 1);   // rd = 1/d per component (exact-division helper)
+    bool dir_safe = false;
     V3 ray_color = mk(1, 1, 1), incoming = mk(0, 0, 0), emitted = mk(0, 0, 0), final_color = mk(0, 0, 0);
     uint32_t rng = 0, pix = 0, slot = 0, sample = 0, bounces = 0;
     float screen_x = 0, screen_y = 0;
@@ -101,6 +158,8 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
     // ---- counters (COUNT build only) ----
     unsigned long long c_rays = 0, c_inner = 0, c_tris = 0, c_hits = 0, c_tex = 0;
     uint32_t c_maxsp = 0, c_pixels = 0;
+    unsigned long long g_iters = 0, g_inner = 0, g_leaf = 0, g_it_inner = 0, g_it_leaf = 0, g_serv = 0, g_serv_lanes = 0;  // lane 0 only
+    unsigned long long g_t_serv = 0, g_t_start = COUNT ? clock64() : 0ull, g_t0 = 0, g_t_mem = 0;
 
     for (;;) {
         const unsigned long long m_t = __ballot(state == ST_T);
@@ -110,6 +169,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
 
         // ---------------- service: shade / finish pixel / fetch pixel / camera ray ------------
         if (n_need != 0u && (n_t == 0u || n_need * 4u >= (n_t + n_need))) {
+            if (COUNT) { g_serv++; g_serv_lanes += n_need; g_t0 = clock64(); }
             bool start_ray = false;
             if (state == ST_S) {
                 bool path_done;
@@ -226,18 +286,35 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
             // ---- start traverse_bvh (ray.rs:84-88, HitInfo::default :214-226) ----
             if (start_ray) {
                 best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;
+                rd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                dir_safe = ray_dir_safe(d);
                 sp = 0; pair = 0;
                 tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;   // root leaf (root_n > 0) or inner (empty range)
                 if (COUNT) c_rays++;
             }
+            if (COUNT) g_t_serv += clock64() - g_t0;
             continue;   // re-evaluate the ballots
         }
 
         // ---------------- one traversal step per traversing lane ---------------------------------
+        if (COUNT) {
+            const unsigned long long m_leaf = __ballot(state == ST_T && tri_cur < tri_end);
+            const uint32_t nl = (uint32_t)__popcll(m_leaf);
+            g_iters++; g_leaf += nl; g_inner += n_t - nl; g_it_leaf += (nl != 0u); g_it_inner += (n_t != nl);
+        }
         if (state == ST_T) {
             const bool leaf = tri_cur < tri_end;
             const float4 *p = leaf ? (sc.tri_pos + (size_t)tri_cur * 3) : (sc.pairs + (size_t)pair * 4);
+            unsigned long long g_ta = 0;
+            if (COUNT && DIAG_STAMPS) g_ta = clock64();
             const float4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];   // tri_pos is padded by one float4
+            // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
+            // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
+            asm volatile("" ::: "memory");
+            if (COUNT && DIAG_STAMPS) {      // diagnostic only: split an iteration into memory wait and the rest
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                g_t_mem += clock64() - g_ta;
+            }
             bool need_pop = false;
             if (leaf) {                                                              // ray.rs:19-67, 90-99
                 const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
@@ -261,8 +338,8 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
                 need_pop = (tri_cur == tri_end);
             } else {                                                                 // ray.rs:108-137
                 const float max_d = best_t * pr.cull_scale;
-                float d1 = slab<CULL>(o, d, r0, r1, max_d);
-                float d2 = slab<CULL>(o, d, r2, r3, max_d);
+                float d1, d2;
+                slab_pair<CULL>(o, d, rd, dir_safe, r0, r1, r2, r3, max_d, d1, d2);
                 uint32_t a1 = __float_as_uint(r0.w), n1 = __float_as_uint(r1.w);
                 uint32_t a2 = __float_as_uint(r2.w), n2 = __float_as_uint(r3.w);
                 uint32_t w2 = 1u;
@@ -320,6 +397,15 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
         atomicAdd(&pr.stats->hits, c_hits);
         atomicAdd(&pr.stats->texel_fetches, c_tex);
         atomicMax(&pr.stats->max_stack, (unsigned long long)c_maxsp);
+        if (lane == 0) {
+            atomicAdd(&pr.stats->d_iters, g_iters); atomicAdd(&pr.stats->d_inner_lanes, g_inner);
+            atomicAdd(&pr.stats->d_leaf_lanes, g_leaf); atomicAdd(&pr.stats->d_iters_inner, g_it_inner);
+            atomicAdd(&pr.stats->d_iters_leaf, g_it_leaf); atomicAdd(&pr.stats->d_services, g_serv);
+            atomicAdd(&pr.stats->d_service_lanes, g_serv_lanes);
+            atomicAdd(&pr.stats->d_cycles_service, g_t_serv);
+            atomicAdd(&pr.stats->d_cycles_total, clock64() - g_t_start);
+            atomicAdd(&pr.stats->d_cycles_mem, g_t_mem);
+        }
     }
     if (c_pixels) atomicAdd(&pr.stats->pixels, (unsigned long long)c_pixels);
 }
@@ -372,6 +458,7 @@ __global__ void debug_eval_kernel(int op, const float *__restrict__ a, const flo
         case 11: { uint32_t s = __float_as_uint(x); V3 v = rand_in_unit_sphere(s); r = (y == 0.0f) ? v.x : (y == 1.0f ? v.y : v.z); } break;
         case 12: r = __uint_as_float(srgb_quantize(x)); break;
         case 13: r = x - truncf(x); break;
+        case 14: r = fdiv_ray(x, y, 1.0f / y); break;                                          // exact-division helper (valid range only)
         default: break;
         }
         out[i] = r;

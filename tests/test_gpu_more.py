@@ -284,3 +284,35 @@ def test_full_size_properties_config_M(rrt, orc):
         parts += int(p.view(np.uint32).astype(np.uint64).sum())
     assert parts == csum                                         # 1080p has no ragged tiles: padding slots stay 0
     assert float(np.isfinite(cul).mean()) == 1.0 and 0.01 < float(cul.mean()) < 5.0
+
+
+def test_fast_division_is_ieee(rrt):
+    """The slab test's per-ray-reciprocal division (pt_kernel.hip fdiv_ray) must equal IEEE a/d bit for bit on its
+    whole guarded range: |d| in [2^-60, 2], |a/d| in (2^-40, 2^100).  Includes quotients engineered to sit on rounding
+    boundaries (a = q*d +- a few ulps) and exactly representable quotients."""
+    lib = rrt.load()
+
+    def dev(op, a, b):
+        out = np.zeros_like(a)
+        assert lib.mipt_debug_eval(op, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data) == 0
+        return out
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    sign = lambda k: rng.choice(np.float32([-1, 1]), k)
+    d = (sign(n) * np.exp2(rng.uniform(-60, 1, n))).astype(np.float32)
+    q = (sign(n) * np.exp2(rng.uniform(-39, 99, n))).astype(np.float32)
+    # 1. random a over the range  2. a = RN(q*d) (quotient near a representable value)  3. +- 1..2 ulps of that
+    with np.errstate(all="ignore"):
+        a_rand = (q.astype(np.float64) * d * np.exp2(rng.uniform(-0.5, 0.5, n))).astype(np.float32)
+        a_exact = (q.astype(np.float64) * d).astype(np.float32)
+        a_near = np.nextafter(a_exact, np.float32(np.inf) * sign(n)).astype(np.float32)
+        # mantissas of all ones / powers of two in the divisor (the classic hard cases for reciprocal iterations)
+        d_hard = d.copy()
+        d_hard[::2] = (d_hard[::2].view(np.uint32) | np.uint32(0x007FFFFF)).view(np.float32)
+        d_hard[1::2] = (d_hard[1::2].view(np.uint32) & np.uint32(0xFF800000)).view(np.float32)
+        for a, dd in ((a_rand, d), (a_exact, d), (a_near, d), (a_rand, d_hard), (a_near, d_hard)):
+            want = (a / dd).astype(np.float32)
+            ok = (np.abs(want) > 2.0 ** -40) & (np.abs(want) < 2.0 ** 100) & (np.abs(dd) >= 2.0 ** -60) & (np.abs(dd) <= 2)
+            got = dev(14, a, dd)
+            assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+            assert ok.mean() > 0.95
