@@ -126,8 +126,8 @@ typedef struct {
     /* wave-occupancy diagnostics [COUNT]: traversal iterations (per wave); sum of lanes on an inner step; sum of lanes on
      * a leaf step; iterations that executed the inner branch; the leaf branch; service passes; lanes serviced;
      * wave-cycles inside service passes; wave-cycles alive; wave-cycles waiting for the traversal loads (only in a
-     * -DMIPT_DIAG_STAMPS=1 build) */
-    uint64_t diag[10];
+     * -DMIPT_DIAG_STAMPS=1 build); wave-cycles between a wave first finding the queue empty and its exit (tail) */
+    uint64_t diag[11];
 } MiptStats;
 
 enum MiptStatus {

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmipt.so")
+LIB_PATH = os.environ.get("MIPT_LIB") or os.path.join(_HERE, "libmipt.so")   # MIPT_LIB: A/B a kernel variant
 
 # ---- numpy views of the reference PODs (reference src/scene.rs:87-146, src/bvh.rs:164-171) ----
 VERTEX = np.dtype([("position", "<f4", 3), ("tex_coord_x", "<f4"), ("normal", "<f4", 3), ("tex_coord_y", "<f4")])
@@ -58,7 +58,7 @@ class MiptStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("rays", C.c_uint64), ("inner_steps", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("texel_fetches", C.c_uint64),
                 ("stack_overflows", C.c_uint64), ("tex_clamped", C.c_uint64), ("max_stack", C.c_uint64),
-                ("pixels", C.c_uint64), ("diag", C.c_uint64 * 10)]
+                ("pixels", C.c_uint64), ("diag", C.c_uint64 * 11)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "diag"}

@@ -137,6 +137,13 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
     uint32_t max_leaf = 0;
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const MiptNode &n = desc->nodes[i];
+        {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (pt_kernel.hip ray_safe)
+            const float lim = 1.0995116e12f;
+            const float *b = &n.bounds_min.x, *c = &n.bounds_max.x;
+            for (int k = 0; k < 3; k++)
+                if (!(fabsf(b[k]) <= lim) || !(fabsf(c[k]) <= lim))
+                    return fail(MIPT_ERR_SCENE_LIMIT, "node %u has a non-finite bound or one beyond 2^40", i);
+        }
         if (n.num_tris > 0) {
             if ((uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris)
                 return fail(MIPT_ERR_BVH, "leaf node %u covers triangles [%u, %u+%u) beyond n_tris=%u", i, n.first_tri_or_child, n.first_tri_or_child, n.num_tris, desc->n_tris);
@@ -306,6 +313,10 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
     pr.aspect = (float)opt->width / (float)opt->height;       // cpu.rs:34
     pr.samples_f = (float)opt->samples;                       // cpu.rs:60
     pr.cull_scale = 1.0f + opt->cull_margin;
+    pr.service_num = 1; pr.service_den = 4; pr.reverse_tiles = 0;
+    if (const char *e = getenv("MIPT_REVERSE_TILES")) pr.reverse_tiles = atoi(e) ? 1u : 0u;
+    if (const char *e = getenv("MIPT_SERVICE_NUM")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_num = (uint32_t)v; }
+    if (const char *e = getenv("MIPT_SERVICE_DEN")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_den = (uint32_t)v; }
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) pr.cam[c * 3 + r] = camera->look_at[c][r];
     pr.cam[9] = camera->position.x; pr.cam[10] = camera->position.y; pr.cam[11] = camera->position.z;
@@ -346,7 +357,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
         stats->tex_clamped = hs.tex_clamped; stats->max_stack = hs.max_stack; stats->pixels = hs.pixels;
         stats->diag[0] = hs.d_iters; stats->diag[1] = hs.d_inner_lanes; stats->diag[2] = hs.d_leaf_lanes;
         stats->diag[3] = hs.d_iters_inner; stats->diag[4] = hs.d_iters_leaf; stats->diag[5] = hs.d_services;
-        stats->diag[6] = hs.d_service_lanes; stats->diag[7] = hs.d_cycles_service; stats->diag[8] = hs.d_cycles_total; stats->diag[9] = hs.d_cycles_mem;
+        stats->diag[6] = hs.d_service_lanes; stats->diag[7] = hs.d_cycles_service; stats->diag[8] = hs.d_cycles_total; stats->diag[9] = hs.d_cycles_mem; stats->diag[10] = hs.d_cycles_tail;
     }
     if (hs.stack_overflows)
         return fail(MIPT_ERR_STACK, "traversal stack overflowed %llu times (capacity %d; the reference panics at 32, ray.rs:85)",

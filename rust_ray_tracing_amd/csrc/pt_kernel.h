@@ -37,7 +37,7 @@ struct DevStats {                 // zeroed before every launch
     // wave-level occupancy diagnostics (COUNT build): traversal iterations, lanes doing inner / leaf work,
     // iterations that ran the inner / leaf branch, service passes, lanes serviced
     unsigned long long d_iters, d_inner_lanes, d_leaf_lanes, d_iters_inner, d_iters_leaf, d_services, d_service_lanes;
-    unsigned long long d_cycles_service, d_cycles_total, d_cycles_mem;   // per-wave s_memtime cycles spent in service passes / alive
+    unsigned long long d_cycles_service, d_cycles_total, d_cycles_mem, d_cycles_tail;   // per-wave s_memtime cycles spent in service passes / alive
 };
 
 struct DevParams {
@@ -49,6 +49,8 @@ struct DevParams {
     float aspect;                           // width as f32 / height as f32 (cpu.rs:34)
     float samples_f;
     float cull_scale;                       // 1 + cull_margin
+    uint32_t reverse_tiles;                 // hand out the tile list back to front (bottom rows first)
+    uint32_t service_num, service_den;      // run the service pass when need/live >= num/den
     float cam[12];                          // look_at columns 0..2 (xyz each), position
     float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
     uint32_t *ovf;                          // traversal-stack overflow area [wave][entry][lane]

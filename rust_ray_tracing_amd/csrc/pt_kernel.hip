@@ -56,8 +56,8 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // r = RN(1/d); per quotient the same quotient refinement the hardware sequence ends with remains --
 //   q0 = a*r; q1 = q0 + (a - q0*d)*r; q2 = q1 + (a - q1*d)*r      (residuals exact in FMA)
 // q1 is faithful, q2 = RN(a/d) (Markstein's theorem) -- PROVIDED nothing under/overflows.  That is guaranteed when
-// |d| in [2^-60, 2] (checked once per ray) and |q| in (2^-40, 2^100) (checked on the results, see slab_pair):
-// then |a| >= 2^-100, so every residual is representable.  Lanes failing the check (a == 0: origin exactly on a
+// |d| in [2^-60, 2], |o| <= 2^40 (checked once per ray; scene bounds <= 2^40 are checked at upload) and
+// |q| > 2^-40 (checked on the results, see slab_pair): then 2^-100 <= |a| <= 2^41, so every residual is representable.  Lanes failing the check (a == 0: origin exactly on a
 // bounding plane; axis-parallel rays; inf/NaN) redo the step with IEEE divisions.  The probe op 14 and
 // tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
 __device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
@@ -65,10 +65,13 @@ __device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
     return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
 }
-__device__ __forceinline__ bool ray_dir_safe(V3 d) {
-    const float lo = 8.6736174e-19f /* 2^-60 */, hi = 2.0f;
+// Per-ray guard: every |d_i| in [2^-60, 2] and every |o_i| <= 2^40.  mipt_scene_create rejects scenes whose bounds
+// exceed 2^40, so |a| = |b - o| <= 2^41 and |q| = |a/d| <= 2^101 < 2^104: no overflow anywhere in fdiv_ray, and no
+// NaN can appear (all operands finite, d != 0).  What is left to check per step is the small side (slab_pair).
+__device__ __forceinline__ bool ray_safe(V3 o, V3 d) {
+    const float lo = 8.6736174e-19f /* 2^-60 */, hi = 2.0f, omax = 1.0995116e12f /* 2^40 */;
     return (fabsf(d.x) >= lo) && (fabsf(d.x) <= hi) && (fabsf(d.y) >= lo) && (fabsf(d.y) <= hi) &&
-           (fabsf(d.z) >= lo) && (fabsf(d.z) <= hi);
+           (fabsf(d.z) >= lo) && (fabsf(d.z) <= hi) && (fabsf(o.x) <= omax) && (fabsf(o.y) <= omax) && (fabsf(o.z) <= omax);
 }
 
 // ray.rs:69-81 on quotients already computed (+ rt_compute.wgsl:348's t_near < max_distance when CULL)
@@ -97,15 +100,13 @@ __device__ __forceinline__ void slab_pair(V3 o, V3 d, V3 rd, bool safe, float4 r
     const float p3 = fdiv_ray(a3, d.x, rd.x), p4 = fdiv_ray(a4, d.y, rd.y), p5 = fdiv_ray(a5, d.z, rd.z);
     const float q0 = fdiv_ray(b0, d.x, rd.x), q1 = fdiv_ray(b1, d.y, rd.y), q2 = fdiv_ray(b2, d.z, rd.z);
     const float q3 = fdiv_ray(b3, d.x, rd.x), q4 = fdiv_ray(b4, d.y, rd.y), q5 = fdiv_ray(b5, d.z, rd.z);
+    // small side: |q| > 2^-40 with |d| >= 2^-60 gives |a| >= 2^-100, so both residuals a - q*d are exactly
+    // representable; a == 0 (origin exactly on a bounding plane) or a denormal difference fails this and goes to
+    // the IEEE path.  (The large side and NaNs are excluded by ray_safe + the scene-bounds limit.)
     const float mn = fminf(fminf(fminf(fabsf(p0), fabsf(p1)), fminf(fabsf(p2), fabsf(p3))),
                            fminf(fminf(fminf(fabsf(p4), fabsf(p5)), fminf(fabsf(q0), fabsf(q1))),
                                  fminf(fminf(fabsf(q2), fabsf(q3)), fminf(fabsf(q4), fabsf(q5)))));
-    const float mx = fmaxf(fmaxf(fmaxf(fabsf(p0), fabsf(p1)), fmaxf(fabsf(p2), fabsf(p3))),
-                           fmaxf(fmaxf(fmaxf(fabsf(p4), fabsf(p5)), fmaxf(fabsf(q0), fabsf(q1))),
-                                 fmaxf(fmaxf(fabsf(q2), fabsf(q3)), fmaxf(fabsf(q4), fabsf(q5)))));
-    // NaN quotients are dropped by fmin/fmax, so test them through the sum as well
-    const float chk = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (q0 + q1)) + ((q2 + q3) + (q4 + q5));
-    const bool ok = safe && (mn > 9.094947e-13f /* 2^-40 */) && (mx < 1.2676506e30f /* 2^100 */) && (chk == chk);
+    const bool ok = safe && (mn > 9.094947e-13f /* 2^-40 */);
     if (ok) {
         d1 = slab_from_t<CULL>(p0, p1, p2, p3, p4, p5, best);
         d2 = slab_from_t<CULL>(q0, q1, q2, q3, q4, q5, best);
@@ -135,8 +136,11 @@ __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t tex, float 
 
 } // namespace
 
+#ifndef MIPT_MIN_WAVES_PER_SIMD
+#define MIPT_MIN_WAVES_PER_SIMD 1
+#endif
 template <bool COUNT, bool CULL>
-__global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, DevParams pr) {
+__global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds][64];
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
     unsigned long long c_rays = 0, c_inner = 0, c_tris = 0, c_hits = 0, c_tex = 0;
     uint32_t c_maxsp = 0, c_pixels = 0;
     unsigned long long g_iters = 0, g_inner = 0, g_leaf = 0, g_it_inner = 0, g_it_leaf = 0, g_serv = 0, g_serv_lanes = 0;  // lane 0 only
-    unsigned long long g_t_serv = 0, g_t_start = COUNT ? clock64() : 0ull, g_t0 = 0, g_t_mem = 0;
+    unsigned long long g_t_serv = 0, g_t_start = COUNT ? clock64() : 0ull, g_t0 = 0, g_t_mem = 0, g_t_first_x = 0;
 
     for (;;) {
         const unsigned long long m_t = __ballot(state == ST_T);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
         if ((n_t | n_need) == 0u) break;
 
         // ---------------- service: shade / finish pixel / fetch pixel / camera ray ------------
-        if (n_need != 0u && (n_t == 0u || n_need * 4u >= (n_t + n_need))) {
+        if (n_need != 0u && (n_t == 0u || n_need * pr.service_den >= (n_t + n_need) * pr.service_num)) {
             if (COUNT) { g_serv++; g_serv_lanes += n_need; g_t0 = clock64(); }
             bool start_ray = false;
             if (state == ST_S) {
@@ -240,15 +244,17 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
                         const unsigned long long wi = base + lane_rank(m_p);
                         if (wi >= pr.total_work) {
                             state = ST_X;
+                            if (COUNT && g_t_first_x == 0) g_t_first_x = clock64();
                         } else {
                             // 8x8 pixel tiles, round-robin over ranks: global tile = local*world + rank
                             const uint32_t lt = (uint32_t)(wi >> 6), p = (uint32_t)wi & 63u;
-                            const uint32_t gt = lt * pr.tile_world + pr.tile_rank;
+                            const uint32_t lt_o = pr.reverse_tiles ? (pr.n_local_tiles - 1u - lt) : lt;
+                            const uint32_t gt = lt_o * pr.tile_world + pr.tile_rank;
                             const uint32_t px = (gt % pr.tiles_x) * 8u + (p & 7u);
                             const uint32_t py = (gt / pr.tiles_x) * 8u + (p >> 3);
                             if (px < pr.width && py < pr.height) {            // ragged edge tiles: skip, stay ST_P
                                 pix = py * pr.width + px;
-                                slot = pr.packed ? (uint32_t)wi : pix;
+                                slot = pr.packed ? (lt_o * 64u + p) : pix;
                                 rng = 987612486u * (pix + 87636354u);                 // cpu.rs:28-29
                                 const uint32_t y = pr.height - py;                    // cpu.rs:32
                                 screen_x = ((((float)px / (float)pr.width) * 2.0f) - 1.0f) * pr.aspect; // cpu.rs:33-34
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
             if (start_ray) {
                 best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;
                 rd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                dir_safe = ray_dir_safe(d);
+                dir_safe = ray_safe(o, d);
                 sp = 0; pair = 0;
                 tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;   // root leaf (root_n > 0) or inner (empty range)
                 if (COUNT) c_rays++;
@@ -297,6 +303,8 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
         }
 
         // ---------------- one traversal step per traversing lane ---------------------------------
+        // (Leaf batching -- parking lanes at leaves until >= N of the wave are there -- was measured and is slower at
+        //  every N: 100.3 ms at N=1 (off) vs 105/112/133 ms at N=8/16/32; every lane's step chain is on the critical path.)
         if (COUNT) {
             const unsigned long long m_leaf = __ballot(state == ST_T && tri_cur < tri_end);
             const uint32_t nl = (uint32_t)__popcll(m_leaf);
@@ -405,6 +413,10 @@ __global__ __launch_bounds__(kBlockThreads) void pt_trace_kernel(DevScene sc, De
             atomicAdd(&pr.stats->d_cycles_service, g_t_serv);
             atomicAdd(&pr.stats->d_cycles_total, clock64() - g_t_start);
             atomicAdd(&pr.stats->d_cycles_mem, g_t_mem);
+        }
+        {   // tail: wave-cycles between the first lane of the wave finding the queue empty and the wave's exit
+            const unsigned long long tx = __shfl(g_t_first_x, (int)(__ffsll((long long)__ballot(g_t_first_x != 0)) - 1));
+            if (lane == 0 && tx != 0) atomicAdd(&pr.stats->d_cycles_tail, clock64() - tx);
         }
     }
     if (c_pixels) atomicAdd(&pr.stats->pixels, (unsigned long long)c_pixels);

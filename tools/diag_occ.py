@@ -17,7 +17,8 @@ for flags in (L.FLAG_COUNT, 0, 0):
     d = st.as_dict()
     print(d)
     if flags:
-        it, il, ll, iti, itl, sv, svl, cs, ct, cm = d["diag"]
+        it, il, ll, iti, itl, sv, svl, cs, ct, cm, ctail = d["diag"]
+        print(f"tail: {ctail/ct:.1%} of wave-cycles are after the wave first saw an empty queue")
         print(f"memory wait per traversal iter {cm/it:.0f} cycles")
         print(f"wave-cycles: service {cs:.3e} of total {ct:.3e} = {cs/ct:.1%}; per service pass {cs/max(sv,1):.0f} cycles; per traversal iter {(ct-cs)/it:.0f} cycles")
         print(f"iters {it:.3e}  inner lanes/iter {il/it:.1f}  leaf lanes/iter {ll/it:.1f}  inner-branch iters {iti/it:.2%}  leaf-branch iters {itl/it:.2%}")
