@@ -40,14 +40,21 @@ enum : uint32_t {
 // leaf -> bit31 | n << 25 | first_tri  (1 <= n <= 63);
 // leaf with n >= 64 -> bit31 | (pair*2 + which)  (n field 0: re-read (a, n) from the pair on pop)
 __device__ __forceinline__ uint32_t encode_child(uint32_t a, uint32_t n, uint32_t pair, uint32_t which) {
-    if (n == 0) return a;
-    if (n < 64u) return 0x80000000u | (n << 25) | a;
-    return 0x80000000u | (pair * 2u + which);
+    const uint32_t leaf = 0x80000000u | ((n < 64u) ? ((n << 25) | a) : (pair * 2u + which));
+    return (n == 0u) ? a : leaf;
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+
+// v_min/v_max without the canonicalising v_max(x,x) hipcc puts in front of fminf/fmaxf (it guards against signalling
+// NaNs; these operands are FMA results).  Semantics are IEEE minNum/maxNum = Rust f32::min/max.
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float min3_abs(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // ---- exact division with a per-ray reciprocal -------------------------------------------------------------
 // The slab test divides by the ray direction 12 times per inner step (ray.rs:70-71) and bit-exactness forbids
@@ -77,10 +84,10 @@ __device__ __forceinline__ bool ray_safe(V3 o, V3 d) {
 // ray.rs:69-81 on quotients already computed (+ rt_compute.wgsl:348's t_near < max_distance when CULL)
 template <bool CULL>
 __device__ __forceinline__ float slab_from_t(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz, float best) {
-    float t1x = fminf(tminx, tmaxx), t1y = fminf(tminy, tmaxy), t1z = fminf(tminz, tmaxz);
-    float t2x = fmaxf(tminx, tmaxx), t2y = fmaxf(tminy, tmaxy), t2z = fmaxf(tminz, tmaxz);
-    float t_near = fmaxf(fmaxf(t1x, t1y), t1z);
-    float t_far = fminf(fminf(t2x, t2y), t2z);
+    float t1x = min_raw(tminx, tmaxx), t1y = min_raw(tminy, tmaxy), t1z = min_raw(tminz, tmaxz);
+    float t2x = max_raw(tminx, tmaxx), t2y = max_raw(tminy, tmaxy), t2z = max_raw(tminz, tmaxz);
+    float t_near = max3_raw(t1x, t1y, t1z);      // max(max(x, y), z): maxNum is associative, NaNs dropped either way
+    float t_far = min3_raw(t2x, t2y, t2z);
     bool ok = (t_near <= t_far) && (t_far > 0.0f);
     if (CULL) ok = ok && (t_near < best);
     return ok ? t_near : kMiss;
@@ -103,9 +110,7 @@ __device__ __forceinline__ void slab_pair(V3 o, V3 d, V3 rd, bool safe, float4 r
     // small side: |q| > 2^-40 with |d| >= 2^-60 gives |a| >= 2^-100, so both residuals a - q*d are exactly
     // representable; a == 0 (origin exactly on a bounding plane) or a denormal difference fails this and goes to
     // the IEEE path.  (The large side and NaNs are excluded by ray_safe + the scene-bounds limit.)
-    const float mn = fminf(fminf(fminf(fabsf(p0), fabsf(p1)), fminf(fabsf(p2), fabsf(p3))),
-                           fminf(fminf(fminf(fabsf(p4), fabsf(p5)), fminf(fabsf(q0), fabsf(q1))),
-                                 fminf(fminf(fabsf(q2), fabsf(q3)), fminf(fabsf(q4), fabsf(q5)))));
+    const float mn = min3_raw(min3_abs(p0, p1, p2), min3_abs(p3, p4, p5), min_raw(min3_abs(q0, q1, q2), min3_abs(q3, q4, q5)));
     const bool ok = safe && (mn > 9.094947e-13f /* 2^-40 */);
     if (ok) {
         d1 = slab_from_t<CULL>(p0, p1, p2, p3, p4, p5, best);
@@ -363,14 +368,16 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                 } else {
                     if (d2 < kMiss) {                                                // ray.rs:133-136
                         const uint32_t e = encode_child(a2, n2, pair, w2);
-                        if (sp < (uint32_t)kStackLds) stk[sp][lane] = e;
-                        else if (sp < (uint32_t)(kStackLds + kStackOvf)) ovf[(size_t)(sp - kStackLds) * 64] = e;
-                        if (sp < (uint32_t)(kStackLds + kStackOvf)) {
+                        if (sp < (uint32_t)kStackLds) {
+                            stk[sp][lane] = e;
                             sp += 1;
-                            if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
+                        } else if (sp < (uint32_t)(kStackLds + kStackOvf)) {
+                            ovf[(size_t)(sp - kStackLds) * 64] = e;
+                            sp += 1;
                         } else {
                             atomicAdd(&pr.stats->stack_overflows, 1ull);             // reference: panic (ray.rs:85)
                         }
+                        if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                     }
                     if (n1 > 0u) { tri_cur = a1; tri_end = a1 + n1; }                // ray.rs:131 node = child_1
                     else { pair = a1; }
