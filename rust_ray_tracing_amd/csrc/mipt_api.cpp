@@ -51,7 +51,7 @@ void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 struct MiptScene {
     int device = 0;
     mipt::DevScene dev{};
-    void *d_pairs = nullptr, *d_tri_pos = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_texs = nullptr,
+    void *d_geom = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_texs = nullptr,
          *d_texels = nullptr;
     // workspace
     mipt::DevStats *d_stats = nullptr;
@@ -71,7 +71,7 @@ namespace {
 void free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_pairs, s->d_tri_pos, s->d_tri_attr, s->d_mats, s->d_texs, s->d_texels,
+    void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_texs, s->d_texels,
                     s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -223,7 +223,16 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
     s->device = device_id;
     s->max_leaf = max_leaf;
     int rc;
-    if ((rc = upload(&s->d_pairs, pairs, 64)) || (rc = upload(&s->d_tri_pos, tri_pos)) || (rc = upload(&s->d_tri_attr, tri_attr)) ||
+    // pairs and tri_pos share one allocation (one buffer descriptor, 32-bit offsets in the kernel)
+    const size_t pairs_bytes = pairs.size() * sizeof(float4), pos_bytes = tri_pos.size() * sizeof(float4);
+    if (pairs_bytes + pos_bytes >= 0xffffffffull) { free_scene(s); return fail(MIPT_ERR_SCENE_LIMIT, "BVH + triangle stream exceed 4 GiB"); }
+    {
+        hipError_t e1 = hipMalloc(&s->d_geom, pairs_bytes + pos_bytes + 64);
+        if (e1 == hipSuccess && pairs_bytes) e1 = hipMemcpy(s->d_geom, pairs.data(), pairs_bytes, hipMemcpyHostToDevice);
+        if (e1 == hipSuccess) e1 = hipMemcpy((char *)s->d_geom + pairs_bytes, tri_pos.data(), pos_bytes, hipMemcpyHostToDevice);
+        if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
+    }
+    if ((rc = upload(&s->d_tri_attr, tri_attr)) ||
         (rc = upload(&s->d_mats, mats, 32)) || (rc = upload(&s->d_texs, texs, 16)) || (rc = upload(&s->d_texels, texels, 16))) {
         free_scene(s);
         return rc;
@@ -237,8 +246,10 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
         free_scene(s);
         return fail(MIPT_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e));
     }
-    s->dev.pairs = (const float4 *)s->d_pairs;
-    s->dev.tri_pos = (const float4 *)s->d_tri_pos;
+    s->dev.pairs = (const float4 *)s->d_geom;
+    s->dev.tri_pos = (const float4 *)((const char *)s->d_geom + pairs_bytes);
+    s->dev.tri_off_bytes = (uint32_t)pairs_bytes;
+    s->dev.geom_bytes = (uint32_t)(pairs_bytes + pos_bytes);
     s->dev.tri_attr = (const float4 *)s->d_tri_attr;
     s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
     s->dev.texs = (const mipt::DevTexture *)s->d_texs;

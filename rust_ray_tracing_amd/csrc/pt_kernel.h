@@ -20,8 +20,9 @@ struct DevMaterial { float base[3]; uint32_t base_tex; float emis[3]; uint32_t e
 struct DevTexture { uint32_t offset, width, height, pad; };
 
 struct DevScene {
-    const float4 *pairs;
-    const float4 *tri_pos;
+    const float4 *pairs;          // = geom: [pairs | tri_pos] live in ONE allocation so the traversal step can address either
+    const float4 *tri_pos;        //   through one buffer descriptor with a 32-bit byte offset (tri_off_bytes = n_pairs * 64)
+    uint32_t tri_off_bytes, geom_bytes;
     const float4 *tri_attr;
     const DevMaterial *mats;
     const DevTexture *texs;

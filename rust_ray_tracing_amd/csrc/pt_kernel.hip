@@ -81,6 +81,13 @@ __device__ __forceinline__ bool ray_safe(V3 o, V3 d) {
            (fabsf(d.z) >= lo) && (fabsf(d.z) <= hi) && (fabsf(o.x) <= omax) && (fabsf(o.y) <= omax) && (fabsf(o.z) <= omax);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <class R>
+__device__ __forceinline__ float4 ldg4(R rsrc, uint32_t byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // ray.rs:69-81 on quotients already computed (+ rt_compute.wgsl:348's t_near < max_distance when CULL)
 template <bool CULL>
 __device__ __forceinline__ float slab_from_t(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz, float best) {
@@ -152,6 +159,8 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
     const uint32_t wib = threadIdx.x >> 6;
     uint32_t(*stk)[64] = s_stack[wib];
     uint32_t *ovf = pr.ovf + ((size_t)blockIdx.x * kWavesPerBlock + wib) * (size_t)(kStackOvf * 64) + lane;
+
+    const auto geom = __builtin_amdgcn_make_buffer_rsrc((void *)sc.pairs, 0, (int)sc.geom_bytes, 0x00020000);
 
     // ---- per-lane path state ----
     uint32_t state = ST_P;
@@ -317,10 +326,12 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
         }
         if (state == ST_T) {
             const bool leaf = tri_cur < tri_end;
-            const float4 *p = leaf ? (sc.tri_pos + (size_t)tri_cur * 3) : (sc.pairs + (size_t)pair * 4);
+            // one buffer descriptor over [pairs | tri_pos], 32-bit byte offset per lane (no 64-bit address math)
+            const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * 48u) : (pair * 64u);
             unsigned long long g_ta = 0;
             if (COUNT && DIAG_STAMPS) g_ta = clock64();
-            const float4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];   // tri_pos is padded by one float4
+            const float4 r0 = ldg4(geom, voff), r1 = ldg4(geom, voff + 16u), r2 = ldg4(geom, voff + 32u),
+                         r3 = ldg4(geom, voff + 48u);                  // tri_pos is padded by one float4
             // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
             // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
             asm volatile("" ::: "memory");
