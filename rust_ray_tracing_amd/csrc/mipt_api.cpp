@@ -22,7 +22,7 @@ static_assert(sizeof(MiptNode) == 32 && offsetof(MiptNode, first_tri_or_child) =
 static_assert(sizeof(MiptMaterial) == 80 && offsetof(MiptMaterial, ior) == 28 && offsetof(MiptMaterial, emission) == 32 &&
                   offsetof(MiptMaterial, roughness) == 44 && offsetof(MiptMaterial, base_color_tex_id) == 56, "Material");
 static_assert(sizeof(MiptCamera) == 80 && offsetof(MiptCamera, position) == 64, "UniformCamera");
-static_assert(sizeof(mipt::DevMaterial) == 32 && sizeof(mipt::DevTexture) == 16, "device records");
+static_assert(sizeof(mipt::DevMaterial) == 64, "device records");
 
 namespace {
 
@@ -51,7 +51,7 @@ void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 struct MiptScene {
     int device = 0;
     mipt::DevScene dev{};
-    void *d_geom = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_texs = nullptr,
+    void *d_geom = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr,
          *d_texels = nullptr;
     // workspace
     mipt::DevStats *d_stats = nullptr;
@@ -71,7 +71,7 @@ namespace {
 void free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_texs, s->d_texels,
+    void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_texels,
                     s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -191,23 +191,28 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
     }
     tri_pos[(size_t)desc->n_tris * 3] = make_float4(0, 0, 0, 0);
     // ---- materials / textures ----
+    struct TexDesc { uint32_t offset, width, height; };
+    std::vector<TexDesc> texs(desc->n_textures);
+    uint64_t n_texels = 0;
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        const MiptTexture &t = desc->textures[i];
+        if (!t.rgba8 || t.width == 0 || t.height == 0) return fail(MIPT_ERR_INVALID_ARG, "texture %u is empty", i);
+        if (n_texels + (uint64_t)t.width * t.height > 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "texture pool exceeds 2^32 texels");
+        texs[i] = {(uint32_t)n_texels, t.width, t.height};
+        n_texels += (uint64_t)t.width * t.height;
+    }
     std::vector<mipt::DevMaterial> mats(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; i++) {
         const MiptMaterial &m = desc->materials[i];
         if ((m.base_color_tex_id != UINT32_MAX && m.base_color_tex_id >= desc->n_textures) ||
             (m.emission_tex_id != UINT32_MAX && m.emission_tex_id >= desc->n_textures))
             return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
-        mats[i] = {{m.base_color.x, m.base_color.y, m.base_color.z}, m.base_color_tex_id,
-                   {m.emission.x, m.emission.y, m.emission.z}, m.emission_tex_id};
-    }
-    std::vector<mipt::DevTexture> texs(desc->n_textures);
-    uint64_t n_texels = 0;
-    for (uint32_t i = 0; i < desc->n_textures; i++) {
-        const MiptTexture &t = desc->textures[i];
-        if (!t.rgba8 || t.width == 0 || t.height == 0) return fail(MIPT_ERR_INVALID_ARG, "texture %u is empty", i);
-        if (n_texels + (uint64_t)t.width * t.height > 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "texture pool exceeds 2^32 texels");
-        texs[i] = {(uint32_t)n_texels, t.width, t.height, 0u};
-        n_texels += (uint64_t)t.width * t.height;
+        mipt::DevMaterial d{};
+        d.base[0] = m.base_color.x; d.base[1] = m.base_color.y; d.base[2] = m.base_color.z;
+        d.emis[0] = m.emission.x; d.emis[1] = m.emission.y; d.emis[2] = m.emission.z;
+        if (m.base_color_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.base_color_tex_id]; d.base_off = t.offset; d.base_w = t.width; d.base_h = t.height; }
+        if (m.emission_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.emission_tex_id]; d.emis_off = t.offset; d.emis_w = t.width; d.emis_h = t.height; }
+        mats[i] = d;
     }
     std::vector<uint32_t> texels((size_t)n_texels);
     for (uint32_t i = 0; i < desc->n_textures; i++)
@@ -233,7 +238,7 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
         if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
     }
     if ((rc = upload(&s->d_tri_attr, tri_attr)) ||
-        (rc = upload(&s->d_mats, mats, 32)) || (rc = upload(&s->d_texs, texs, 16)) || (rc = upload(&s->d_texels, texels, 16))) {
+        (rc = upload(&s->d_mats, mats, 64)) || (rc = upload(&s->d_texels, texels, 16))) {
         free_scene(s);
         return rc;
     }
@@ -252,7 +257,6 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
     s->dev.geom_bytes = (uint32_t)(pairs_bytes + pos_bytes);
     s->dev.tri_attr = (const float4 *)s->d_tri_attr;
     s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
-    s->dev.texs = (const mipt::DevTexture *)s->d_texs;
     s->dev.texels = (const uint32_t *)s->d_texels;
     s->dev.n_pairs = n_pairs; s->dev.n_tris = desc->n_tris; s->dev.n_mats = desc->n_materials; s->dev.n_texs = desc->n_textures;
     // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0

@@ -13,11 +13,16 @@ namespace mipt {
 // tri_pos  : n_tris x 48 B intersection stream {v0.xyz, e1.xyz, e2.xyz, 3 pad words},
 //            e1 = v1 - v0, e2 = v2 - v0 rounded once on the host exactly as ray.rs:24-25 does.
 // tri_attr : n_tris x 64 B shading stream {n0,n1,n2 (9 f32), uv0,uv1,uv2 (6 f32), material_id}.
-// mats     : n_materials x 32 B {base_color.xyz, base_color_tex_id, emission.xyz, emission_tex_id}
-//            -- the only Material fields cpu/ray.rs:162-176 reads.
-// texs     : n_textures x 16 B {texel offset into `texels`, width, height, 0}; texels = RGBA8 as u32.
-struct DevMaterial { float base[3]; uint32_t base_tex; float emis[3]; uint32_t emis_tex; };
-struct DevTexture { uint32_t offset, width, height, pad; };
+// mats     : n_materials x 64 B {base_color.xyz, emission.xyz} -- the only Material fields cpu/ray.rs:162-176 reads --
+//            plus the two textures' {texel offset into `texels`, width, height} inlined; texels = RGBA8 as u32.
+// 64 B: the texture descriptors (texel offset, width, height) ride in the material record, so a textured hit costs
+// attr -> material -> texel (three dependent fetches) instead of four.  tex_w == 0 means "no texture" (u32::MAX id).
+struct DevMaterial {
+    float base[3]; uint32_t base_off;
+    float emis[3]; uint32_t emis_off;
+    uint32_t base_w, base_h, emis_w, emis_h;
+    uint32_t pad[4];
+};
 
 struct DevScene {
     const float4 *pairs;          // = geom: [pairs | tri_pos] live in ONE allocation so the traversal step can address either
@@ -25,7 +30,6 @@ struct DevScene {
     uint32_t tri_off_bytes, geom_bytes;
     const float4 *tri_attr;
     const DevMaterial *mats;
-    const DevTexture *texs;
     const uint32_t *texels;
     uint32_t n_pairs, n_tris, n_mats, n_texs;
     uint32_t root_a, root_n;      // root node: leaf (root_n > 0: tris [root_a, root_a+root_n)) or inner (pair 0)

@@ -26,7 +26,6 @@ constexpr bool DIAG_STAMPS = MIPT_DIAG_STAMPS != 0;   // counting build only: in
 constexpr float kMiss = 1e30f;                     // ray.rs:79,217
 constexpr uint32_t kNoTri = 0xffffffffu;
 constexpr uint32_t kFrontBit = 0x80000000u;
-constexpr uint32_t kNoTex = 0xffffffffu;
 
 enum : uint32_t {
     ST_T = 0,   // traversing
@@ -128,22 +127,28 @@ __device__ __forceinline__ void slab_pair(V3 o, V3 d, V3 rd, bool safe, float4 r
     }
 }
 
+// u8 -> f32 / 255.0 (vec3.rs:252-260) with the same exact two-correction quotient as fdiv_ray: the numerator is an
+// integer in [0, 255] and the divisor the constant 255, so no range guard is needed (0 gives 0 exactly);
+// tests/test_gpu_more.py checks all 256 values against IEEE division.
+__device__ __forceinline__ float u8_over_255(uint32_t k) {
+    return fdiv_ray((float)k, 255.0f, 0.0039215688593685627f /* RN(1/255) */);
+}
+
 // texture.rs:33-38; out-of-range indices (reference: panic) are clamped and counted
-__device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t tex, float u, float v, DevStats *st) {
-    DevTexture t = sc.texs[tex];
+__device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uint32_t width, uint32_t height, float u, float v, DevStats *st) {
     float fu = u - truncf(u), fv = v - truncf(v);                  // f32::fract
-    float fi = fu * (float)t.width, fj = fv * (float)t.height;
+    float fi = fu * (float)width, fj = fv * (float)height;
     // Rust `as i32`: saturating, NaN -> 0
     long long i = (fi != fi) ? 0ll : (fi >= 2147483648.0f ? 2147483647ll : (fi <= -2147483648.0f ? -2147483648ll : (long long)(int)fi));
     long long j = (fj != fj) ? 0ll : (fj >= 2147483648.0f ? 2147483647ll : (fj <= -2147483648.0f ? -2147483648ll : (long long)(int)fj));
-    long long index = i + j * (long long)t.width;
-    long long n = (long long)t.width * (long long)t.height;
+    long long index = i + j * (long long)width;
+    long long n = (long long)width * (long long)height;
     if (index < 0 || index >= n) {
         index = index < 0 ? 0 : n - 1;
         atomicAdd(&st->tex_clamped, 1ull);
     }
-    uint32_t px = sc.texels[(size_t)t.offset + (size_t)index];
-    return mk((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f); // vec3.rs:252-260
+    uint32_t px = sc.texels[(size_t)offset + (size_t)index];
+    return mk(u8_over_255(px & 255u), u8_over_255((px >> 8) & 255u), u8_over_255((px >> 16) & 255u)); // vec3.rs:252-260
 }
 
 } // namespace
@@ -203,14 +208,14 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                     const float uvy = ((a2.z * w) + (a3.x * u)) + (a3.z * v);
                     const V3 point = o + d * best_t;                                // ray.rs:60
                     const DevMaterial m = sc.mats[__float_as_uint(a3.w)];           // ray.rs:153-154
-                    if (m.base_tex != kNoTex) {                                     // ray.rs:162-169
-                        ray_color = ray_color * texel_rgb(sc, m.base_tex, uvx, uvy, pr.stats);
+                    if (m.base_w != 0u) {                                           // ray.rs:162-169
+                        ray_color = ray_color * texel_rgb(sc, m.base_off, m.base_w, m.base_h, uvx, uvy, pr.stats);
                         if (COUNT) c_tex++;
                     } else {
                         ray_color = ray_color * mk(m.base[0], m.base[1], m.base[2]);
                     }
-                    if (m.emis_tex != kNoTex) {                                     // ray.rs:170-176
-                        emitted = emitted + texel_rgb(sc, m.emis_tex, uvx, uvy, pr.stats);
+                    if (m.emis_w != 0u) {                                           // ray.rs:170-176
+                        emitted = emitted + texel_rgb(sc, m.emis_off, m.emis_w, m.emis_h, uvx, uvy, pr.stats);
                         if (COUNT) c_tex++;
                     } else {
                         emitted = emitted + mk(m.emis[0], m.emis[1], m.emis[2]);
@@ -488,7 +493,8 @@ __global__ void debug_eval_kernel(int op, const float *__restrict__ a, const flo
         case 11: { uint32_t s = __float_as_uint(x); V3 v = rand_in_unit_sphere(s); r = (y == 0.0f) ? v.x : (y == 1.0f ? v.y : v.z); } break;
         case 12: r = __uint_as_float(srgb_quantize(x)); break;
         case 13: r = x - truncf(x); break;
-        case 14: r = fdiv_ray(x, y, 1.0f / y); break;                                          // exact-division helper (valid range only)
+        case 14: r = fdiv_ray(x, y, 1.0f / y); break;
+        case 15: r = u8_over_255(__float_as_uint(x)); break;                                          // exact-division helper (valid range only)
         default: break;
         }
         out[i] = r;

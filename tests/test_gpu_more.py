@@ -316,3 +316,12 @@ def test_fast_division_is_ieee(rrt):
             got = dev(14, a, dd)
             assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
             assert ok.mean() > 0.95
+
+
+def test_u8_over_255_is_ieee(rrt):
+    """Texel unpack (vec3.rs:252-260): the kernel's 5-instruction quotient must equal (k as f32) / 255.0 for all 256 bytes."""
+    k = np.arange(256, dtype=np.uint32)
+    out = np.zeros(256, dtype=np.float32)
+    assert rrt.load().mipt_debug_eval(15, k.view(np.float32).ctypes.data, None, 256, out.ctypes.data) == 0
+    want = k.astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
