@@ -44,6 +44,24 @@ def algorithmic_bytes(st: dict, n_samples: int) -> int:
             + 4 * st["texel_fetches"] + 12 * n_samples)
 
 
+def pmc_traffic_bytes(n_tris_requested, w, h, spp, depth, traversal):
+    """HBM-side bytes per launch of the trace kernel from the committed rocprofv3 PMC summary (a separate --pmc run of
+    this same command, tools/pmc.sh): FETCH_SIZE [KiB] x 1024 x 2 (gfx950 counts a 128-B line fill as 64 B --
+    MI355X_MICROARCH.md, HBM; confirmed by TCC_MISS_sum x 128 B) + WRITE_SIZE [KiB] x 1024.  Only valid for the
+    configuration it was measured on (the default config M); otherwise None."""
+    if (n_tris_requested, w, h, spp, depth, traversal) != (10_000_000, 1920, 1080, 8, 64, "culled"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary_final.csv")
+    try:
+        vals = {}
+        for line in open(path).read().splitlines()[1:]:
+            parts = line.split(",")
+            vals[parts[1]] = float(parts[2])
+        return int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
+    except Exception:
+        return None
+
+
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -187,7 +205,9 @@ def main():
                    "sharding": f"8x8 image tiles round-robin over {world} rank(s)" + (", one RCCL all-gather of packed tile slices per frame" if packed else ""),
                    "rays_per_frame": tot["rays"], "paths_per_frame": n_pix * spp},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic_bytes(args.tris, w, h, spp, depth, args.traversal) if world == 1 else None,
+                     "traffic_note": "bytes per launch, rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate run: profiles/r1_pmc_summary_final.csv",
                      "kernel": "pt_trace_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_ray": round(alg_bytes / max(local_counts["rays"], 1), 1),
