@@ -8,8 +8,8 @@
 // Deviations, both documented in DESIGN.md:
 //  * materials keep INSERTION order (the reference iterates a HashMap, so its material ids are
 //    a per-process random permutation -- src/loader/obj.rs:81-90; results are unaffected);
-//  * map_* texture lines need an image decoder (the `image` crate, not vendored): only binary
-//    PPM (P6) files are decoded here; other formats are reported and skipped.
+//  * map_* texture lines need an image decoder (the `image` crate, not vendored): PNG (png_decode.cpp) and
+//    binary PPM (P6) files are decoded here; other formats (JPEG ...) are reported and skipped.
 #include "../../include/mipt.h"
 
 #include <array>
@@ -24,6 +24,7 @@
 #include <vector>
 
 void mipt_internal_set_error(const char *msg);   // mipt_api.cpp: feeds mipt_last_error()
+namespace mipt_png { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
 
 namespace {
 
@@ -137,11 +138,25 @@ bool load_ppm(const std::string &path, Tex *t) {
     return true;
 }
 
+// Texture::load for PNG: decode, flipv(), RGBA8 (texture.rs:18)
+bool load_png(const std::string &path, Tex *t, std::string *err) {
+    std::vector<uint8_t> top_down;
+    if (!mipt_png::decode(path, &t->w, &t->h, &top_down, err)) return false;
+    t->rgba.resize(top_down.size());
+    const size_t row = (size_t)t->w * 4;
+    for (uint32_t y = 0; y < t->h; y++) memcpy(&t->rgba[(size_t)y * row], &top_down[(size_t)(t->h - 1 - y) * row], row);
+    t->hash = djb2(t->rgba);
+    return true;
+}
+
 // obj.rs:267-309
 void load_texture(const std::string &path, MiptObj *obj, uint32_t *slot) {
     Tex t;
-    if (!load_ppm(path, &t)) {
-        fprintf(stderr, "[mipt] texture '%s' skipped: only binary PPM (P6) is decoded in this build\n", path.c_str());
+    std::string err;
+    const bool is_png = path.size() > 4 && (path.compare(path.size() - 4, 4, ".png") == 0 || path.compare(path.size() - 4, 4, ".PNG") == 0);
+    if (!(is_png ? load_png(path, &t, &err) : load_ppm(path, &t))) {
+        // Texture::load returns None when the file is missing (texture.rs:14-17); undecodable formats are skipped too
+        fprintf(stderr, "[mipt] texture '%s' skipped: %s\n", path.c_str(), is_png ? err.c_str() : "only PNG and binary PPM (P6) are decoded in this build (no JPEG)");
         return;
     }
     for (size_t i = 0; i < obj->textures.size(); i++)

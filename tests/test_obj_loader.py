@@ -64,3 +64,82 @@ def test_mtl_blank_line_terminates_material_and_ppm_texture(rrt, tmp_path):
     assert len(sc.textures) == 1 and sc.materials["a"]["base_color_tex_id"] == 0
     # Texture::load flips vertically (texture.rs:18): stored row 0 is the file's last row
     assert sc.textures[0][0, 0].tolist() == [0, 0, 255, 255] and sc.textures[0][1, 0].tolist() == [255, 0, 0, 255]
+
+
+def _png(path, arr, ctype, filters=None, palette=None, trns=None, depth=8, chunk=7777):
+    """Writes a PNG with Python's zlib (dynamic-Huffman deflate) and explicit per-row filter types."""
+    import struct
+    import zlib
+    h, w = arr.shape[:2]
+    rows = arr.reshape(h, -1).astype(np.uint8)
+    bpp = rows.shape[1] // w
+    raw = bytearray()
+    prev = np.zeros(rows.shape[1], dtype=np.int32)
+    for y in range(h):
+        ft = (filters or [0])[y % len(filters or [0])]
+        cur = rows[y].astype(np.int32)
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 0: enc = cur
+        elif ft == 1: enc = cur - a
+        elif ft == 2: enc = cur - prev
+        elif ft == 3: enc = cur - ((a + prev) >> 1)
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            enc = cur - pred
+        raw.append(ft)
+        raw += (enc & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def ch(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    z = zlib.compress(bytes(raw), 9)
+    out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        out += ch(b"PLTE", bytes(palette))
+    if trns is not None:
+        out += ch(b"tRNS", bytes(trns))
+    for i in range(0, len(z), chunk):                      # several IDAT chunks
+        out += ch(b"IDAT", z[i:i + chunk])
+    out += ch(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+def test_png_textures_all_colour_types_and_filters(rrt, tmp_path):
+    """map_Kd PNGs (texture.rs:13-31 via the built-in decoder): RGBA / RGB / grey / grey+alpha / palette+tRNS, all five
+    scanline filters, multi-chunk IDAT; stored v-flipped like Texture::load."""
+    rng = np.random.default_rng(9)
+    w, h = 37, 21
+    grad = (np.add.outer(np.arange(h) * 5, np.arange(w) * 3) % 256).astype(np.uint8)
+    rgba = np.stack([grad, grad.T[:h, :w] if grad.T.shape == grad.shape else grad[::-1], rng.integers(0, 256, (h, w), dtype=np.uint8),
+                     rng.integers(0, 256, (h, w), dtype=np.uint8)], axis=-1)
+    idx = rng.integers(0, 5, (h, w), dtype=np.uint8)
+    pal = rng.integers(0, 256, 15).astype(np.uint8)
+    trns = [10, 200, 255]
+    cases = {
+        "rgba": (rgba, 6, rgba),
+        "rgb": (rgba[..., :3], 2, np.concatenate([rgba[..., :3], np.full((h, w, 1), 255, np.uint8)], -1)),
+        "grey": (rgba[..., 0], 0, np.stack([rgba[..., 0]] * 3 + [np.full((h, w), 255, np.uint8)], -1)),
+        "ga": (rgba[..., [0, 3]], 4, np.stack([rgba[..., 0]] * 3 + [rgba[..., 3]], -1)),
+        "pal": (idx, 3, np.concatenate([pal.reshape(5, 3)[idx], np.array(trns + [255, 255], np.uint8)[idx][..., None]], -1)),
+    }
+    mtl, obj = [], ["mtllib t.mtl", "v 0 0 0", "v 1 0 0", "v 0 1 0"]
+    for name, (arr, ctype, _) in cases.items():
+        _png(str(tmp_path / f"{name}.png"), arr, ctype, filters=[0, 1, 2, 3, 4], palette=pal if ctype == 3 else None,
+             trns=trns if ctype == 3 else None, chunk=97)
+        mtl.append(f"newmtl m_{name}\nmap_Kd {name}.png\n")
+        obj += [f"usemtl m_{name}", "f 1 2 3"]
+    (tmp_path / "t.mtl").write_text("\n".join(mtl))
+    (tmp_path / "t.obj").write_text("\n".join(obj) + "\n")
+    sc = rrt.Scene.load(str(tmp_path / "t.obj"))
+    assert sc is not None and len(sc.textures) == len(cases)
+    for name, (_, _, want) in cases.items():
+        tid = int(sc.materials[f"m_{name}"]["base_color_tex_id"])
+        assert tid != 0xFFFFFFFF
+        assert np.array_equal(sc.textures[tid], want[::-1]), name          # flipv(): stored row 0 = bottom image row
+    # a corrupt PNG is skipped like a missing texture (Texture::load -> None), the scene still loads
+    (tmp_path / "rgba.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
+    sc2 = rrt.Scene.load(str(tmp_path / "t.obj"))
+    assert sc2 is not None and int(sc2.materials["m_rgba"]["base_color_tex_id"]) == 0xFFFFFFFF
