@@ -95,7 +95,9 @@ enum MiptTraversal {
 enum MiptFlags {
     MIPT_FLAG_COUNT  = 1u << 0,   /* counting build: fill rays / inner_steps / tri_tests / ... in MiptStats */
     MIPT_FLAG_PACKED = 1u << 1,   /* tile-sharded output is rank-packed (tile-major) instead of full-frame */
-    MIPT_FLAG_SUM    = 1u << 2    /* hdr = sum over samples (no division): sample-sharded accumulation */
+    MIPT_FLAG_SUM    = 1u << 2,   /* hdr = sum over samples (no division): sample-sharded accumulation */
+    MIPT_FLAG_ACCUM  = 1u << 3    /* with SUM, device buffers only: hdr += this call's samples (progressive rendering,
+                                   * the resumable form of the per-sample loop at gpu.rs:17-77) */
 };
 
 typedef struct {
@@ -173,6 +175,11 @@ int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height
  * 1 for a buffer that already holds the mean). */
 int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor,
                         uint8_t *d_rgba8, void *hip_stream);
+
+/* The wgpu backend's post-process pass (pp_compute.wgsl:7-34): radiance / divisor, clamped to [0,1] (its accumulator is
+ * rgba16unorm), linear_to_srgb, THEN aces_filmic, written as RGBA16 unorm (4 x u16 per pixel, alpha 65535) -- the pixel
+ * format Renderer::render saves (renderer.rs:67-73, ColorType::Rgba16).  The CPU backend's epilogue is mipt_tonemap_device. */
+int mipt_postprocess_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint16_t *d_rgba16, void *hip_stream);
 
 /* ---- host-side restatements of the scene model that feeds the path ------------------- */
 

@@ -87,11 +87,21 @@ def load() -> C.CDLL:
         getattr(lib, name).restype = f32
     lib.orc_shim_powf.argtypes = [f32, f32]
     lib.orc_shim_powf.restype = f32
+    lib.orc_postprocess.argtypes = [vp, C.c_uint64, f32, C.c_int, vp]
+    lib.orc_postprocess.restype = None
     lib.orc_trace_ray.argtypes = [vp, u32, vp, u32, vp, u32, C.POINTER(OrcTexture), u32, C.POINTER(f32 * 3), C.POINTER(f32 * 3),
                                   u32, C.POINTER(u32), C.c_int, C.c_int, C.POINTER(f32 * 3)]
     lib.orc_trace_ray.restype = None
     _lib = lib
     return lib
+
+
+def postprocess(hdr, divisor=1.0, libm=LIBM_SHIM):
+    """pp_compute.wgsl on an [h,w,3] f32 frame -> [h,w,4] uint16."""
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    out = np.zeros(hdr.shape[:-1] + (4,), dtype=np.uint16)
+    load().orc_postprocess(hdr.ctypes.data, hdr.size // 3, divisor, libm, out.ctypes.data)
+    return out
 
 
 def _tex_array(textures):

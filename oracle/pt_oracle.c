@@ -240,6 +240,26 @@ void orc_quantize(const float in[3], uint8_t out[3]) { /* vec3.rs:262-270; NaN -
         out[i] = (c != c) ? 0 : (uint8_t)c;
     }
 }
+/* pp_compute.wgsl:7-34 -- linear_to_srgb THEN aces_filmic on an rgba16unorm accumulator (clamped to [0,1]), stored
+ * as unorm16 = floor(x*65535 + 0.5).  One rounded f32 op per WGSL operator. */
+void orc_postprocess(const float *hdr, uint64_t n_pixels, float divisor, int libm, uint16_t *out) {
+    for (uint64_t i = 0; i < n_pixels; i++) {
+        for (int k = 0; k < 3; k++) {
+            float v = hdr[i * 3 + k];
+            if (divisor != 1.0f) v = v / divisor;
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            float lin[3] = {v, v, v}, srgb[3];
+            orc_linear_to_srgb(lin, libm, srgb);
+            const float x = srgb[0];
+            const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+            float y = (x * (a * x + b)) / (x * (c * x + d) + e);
+            y = fminf(fmaxf(y, 0.0f), 1.0f);
+            out[i * 4 + k] = (uint16_t)floorf(y * 65535.0f + 0.5f);
+        }
+        out[i * 4 + 3] = 65535;
+    }
+}
+
 static inline int32_t f32_as_i32(float f) {           /* Rust `as i32`: saturating, NaN -> 0 */
     if (f != f) return 0;
     if (f >= 2147483648.0f) return INT32_MAX;

@@ -120,6 +120,9 @@ uint32_t orc_debug_pixel(const OrcTriangle *tris, uint32_t n_tris, const OrcNode
                          const OrcCamera *camera, const OrcOptions *opt, uint64_t pixel_index,
                          float *records, uint32_t rec_cap, float out_rgb[3]);
 
+/* pp_compute.wgsl:7-34 (sRGB then ACES filmic, unorm16 RGBA) */
+void orc_postprocess(const float *hdr, uint64_t n_pixels, float divisor, int libm, uint16_t *out);
+
 /* ---- small entry points for the known-answer tests ---- */
 uint32_t orc_pixel_seed(uint32_t index);                        /* cpu.rs:28-29 */
 uint32_t orc_sample_seed(uint32_t s, uint32_t x, uint32_t y);   /* rt_compute.wgsl:102 */

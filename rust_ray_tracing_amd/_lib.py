@@ -30,7 +30,7 @@ NO_TEXTURE = 0xFFFFFFFF
 
 SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
-FLAG_COUNT, FLAG_PACKED, FLAG_SUM = 1, 2, 4
+FLAG_COUNT, FLAG_PACKED, FLAG_SUM, FLAG_ACCUM = 1, 2, 4, 8
 CULL_MARGIN_SAFE = 0.0078125  # MIPT_CULL_MARGIN_SAFE
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_SCENE_LIMIT, ERR_BVH, ERR_IO, ERR_STACK = 0, -1, -2, -3, -4, -5, -6
@@ -69,7 +69,7 @@ class MiptStats(C.Structure):
 # every symbol include/mipt.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "mipt_scene_create", "mipt_scene_destroy", "mipt_render", "mipt_render_device",
-    "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_bvh_build",
+    "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_postprocess_device", "mipt_bvh_build",
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
     "mipt_device_count", "mipt_debug_eval", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
 ]
@@ -107,6 +107,8 @@ def load() -> C.CDLL:
     lib.mipt_unpack_tiles.restype = C.c_int
     lib.mipt_tonemap_device.argtypes = [vp, u64, f32, vp, vp]
     lib.mipt_tonemap_device.restype = C.c_int
+    lib.mipt_postprocess_device.argtypes = [vp, u64, f32, vp, vp]
+    lib.mipt_postprocess_device.restype = C.c_int
     lib.mipt_bvh_build.argtypes = [vp, u32, vp, u32, C.POINTER(u32), u32]
     lib.mipt_bvh_build.restype = C.c_int
     lib.mipt_camera_from_pose.argtypes = [C.POINTER(f32 * 3), f32, f32, vp]

@@ -310,6 +310,8 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
 
     const uint32_t world = opt->tile_world ? opt->tile_world : 1u;
     const bool packed = (opt->flags & MIPT_FLAG_PACKED) != 0 && world > 1;
+    if ((opt->flags & MIPT_FLAG_ACCUM) && !(opt->flags & MIPT_FLAG_SUM))
+        return fail(MIPT_ERR_INVALID_ARG, "MIPT_FLAG_ACCUM needs MIPT_FLAG_SUM (a running sum, divided once at the end)");
     if (d_rgba8 && (packed || (opt->flags & MIPT_FLAG_SUM)))
         return fail(MIPT_ERR_INVALID_ARG, "RGBA8 output needs a full-frame mean buffer (not PACKED / SUM)");
 
@@ -319,6 +321,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
     pr.sample_begin = opt->sample_begin ? opt->sample_begin : 1u;
     pr.sum_only = (opt->flags & MIPT_FLAG_SUM) ? 1u : 0u;
     pr.packed = packed ? 1u : 0u;
+    pr.accumulate = (opt->flags & MIPT_FLAG_ACCUM) ? 1u : 0u;
     pr.tile_rank = opt->tile_rank; pr.tile_world = world;
     pr.tiles_x = (opt->width + 7u) / 8u; pr.tiles_y = (opt->height + 7u) / 8u;
     const uint64_t tiles = (uint64_t)pr.tiles_x * pr.tiles_y;
@@ -385,6 +388,7 @@ int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *o
     if (!scene) return fail(MIPT_ERR_INVALID_ARG, "mipt_render: null scene");
     int rc = validate_options(opt);
     if (rc) return rc;
+    if (opt->flags & MIPT_FLAG_ACCUM) return fail(MIPT_ERR_INVALID_ARG, "MIPT_FLAG_ACCUM needs a caller-owned device buffer: use mipt_render_device");
     HIP_TRY(hipSetDevice(scene->device));
     const uint32_t world = opt->tile_world ? opt->tile_world : 1u;
     const bool packed = (opt->flags & MIPT_FLAG_PACKED) != 0 && world > 1;
@@ -417,6 +421,12 @@ int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height
 int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint8_t *d_rgba8, void *hip_stream) {
     if (!d_hdr_rgb || !d_rgba8 || n_pixels == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_tonemap_device: bad argument");
     HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, n_pixels, divisor, d_rgba8, (hipStream_t)hip_stream));
+    return MIPT_OK;
+}
+
+int mipt_postprocess_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint16_t *d_rgba16, void *hip_stream) {
+    if (!d_hdr_rgb || !d_rgba16 || n_pixels == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_postprocess_device: bad argument");
+    HIP_TRY(mipt::launch_postprocess(d_hdr_rgb, n_pixels, divisor, d_rgba16, (hipStream_t)hip_stream));
     return MIPT_OK;
 }
 

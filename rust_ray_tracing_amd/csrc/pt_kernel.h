@@ -48,6 +48,7 @@ struct DevStats {                 // zeroed before every launch
 struct DevParams {
     uint32_t width, height, samples, max_depth;
     uint32_t seed_mode, sample_begin, sum_only, packed;
+    uint32_t accumulate, pad1;              // accumulate: hdr += this call's result (progressive rendering)
     uint32_t tile_rank, tile_world, tiles_x, tiles_y;
     uint32_t n_local_tiles, pad0;
     unsigned long long total_work;          // n_local_tiles * 64
@@ -78,6 +79,8 @@ hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,
                           uint8_t *rgba8, hipStream_t stream);
 
+hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, float divisor, uint16_t *rgba16,
+                              hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, unsigned long long n, float *out,
                              hipStream_t stream);
 

@@ -242,6 +242,9 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                     } else {
                         if (!pr.sum_only) final_color = final_color / pr.samples_f;  // cpu.rs:60
                         float *dst = pr.hdr + (size_t)slot * 3;
+                        if (pr.accumulate) {      // progressive rendering: add this call's samples to the running sum
+                            final_color = mk(dst[0] + final_color.x, dst[1] + final_color.y, dst[2] + final_color.z);
+                        }
                         dst[0] = final_color.x; dst[1] = final_color.y; dst[2] = final_color.z;
                         c_pixels++;
                         state = ST_P;
@@ -505,6 +508,38 @@ __global__ void debug_eval_kernel(int op, const float *__restrict__ a, const flo
 
 hipError_t launch_debug_eval(int op, const float *a, const float *b, unsigned long long n, float *out, hipStream_t stream) {
     hipLaunchKernelGGL(debug_eval_kernel, dim3(1024), dim3(256), 0, stream, op, a, b, n, out);
+    return hipGetLastError();
+}
+
+// ---- pp_compute.wgsl:7-34: linear_to_srgb, THEN aces_filmic, stored as rgba16unorm -------------------------------
+// One rounded f32 operation per WGSL operator (WGSL leaves FMA fusion to the implementation: unpinned); pow through
+// the same shim as the sRGB epilogue; unorm16 = floor(x * 65535 + 0.5).
+__device__ __forceinline__ float pp_channel(float c) {
+    const float cutoff = (c < 0.0031308f) ? 1.0f : 0.0f;
+    const float higher = 1.055f * shim_powf(c, 1.0f / 2.4f) - 0.055f;
+    const float lower = c * 12.92f;
+    const float x = (higher * (1.0f - cutoff)) + lower * cutoff;          // mix(higher, lower, cutoff)
+    const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
+    float y = (x * (a * x + b)) / (x * (cc * x + d) + e);
+    y = fminf(fmaxf(y, 0.0f), 1.0f);                                      // clamp; NaN -> 0 like WGSL clamp(min(max()))
+    return y;
+}
+__global__ void postprocess_kernel(const float *__restrict__ hdr, unsigned long long n, float divisor, uint16_t *__restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        float c[3] = {hdr[i * 3 + 0], hdr[i * 3 + 1], hdr[i * 3 + 2]};
+        for (int k = 0; k < 3; k++) {
+            float v = c[k];
+            if (divisor != 1.0f) v = v / divisor;
+            v = fminf(fmaxf(v, 0.0f), 1.0f);       // the rt texture is rgba16unorm: radiance is clamped to [0,1] before pp (gpu.rs:140)
+            out[i * 4 + k] = (uint16_t)floorf(pp_channel(v) * 65535.0f + 0.5f);
+        }
+        out[i * 4 + 3] = 65535;
+    }
+}
+
+hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, float divisor, uint16_t *rgba16, hipStream_t stream) {
+    hipLaunchKernelGGL(postprocess_kernel, dim3(2048), dim3(256), 0, stream, hdr, n_pixels, divisor, rgba16);
     return hipGetLastError();
 }
 

@@ -251,6 +251,22 @@ def write_ppm(path: str, rgb: np.ndarray) -> None:
         f.write(np.ascontiguousarray(rgb, dtype=np.uint8).tobytes())
 
 
+def write_png_rgba16(path: str, rgba16: np.ndarray) -> None:
+    """RGBA16 PNG (big-endian samples) -- the format Renderer::render saves (renderer.rs:67-73, ColorType::Rgba16)."""
+    import struct
+    import zlib
+    h, w, _ = rgba16.shape
+    be = np.ascontiguousarray(rgba16, dtype=np.uint16).astype(">u2")
+    raw = b"".join(b"\x00" + be[y].tobytes() for y in range(h))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 6, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def write_png_rgba8(path: str, rgba: np.ndarray) -> None:
     """Minimal PNG writer (zlib + CRC from the stdlib).  The reference saves through image::save_buffer
     (renderer.rs:67-73) as Rgba16 -- which cannot hold the CPU path's RGBA8 bytes; this

@@ -370,3 +370,45 @@ def test_config5_sample_sharded_4096(rrt, orc):
     whole, _, _ = orc.render(sc.tris, sc.bvh_nodes, m, sc.textures, sc.camera.uniform, w, h, spp, depth, seed_mode=1, sum_only=1,
                              pix_stride=stride, want_rgba8=False)
     assert np.allclose(total.reshape(-1, 3)[idx], whole.reshape(-1, 3)[idx], rtol=1e-5, atol=1e-5)
+
+
+def test_progressive_accumulation_and_postprocess(rrt, orc, tmp_path):
+    """resumable per-sample accumulation (gpu.rs:17-77 without the rgba16unorm quantisation), the
+    sRGB-then-ACES post-process pass (pp_compute.wgsl:7-34) and RGBA16 output (renderer.rs:67-73)."""
+    import torch
+    from rust_ray_tracing_amd import _lib as L
+    from rust_ray_tracing_amd import host
+    lib = rrt.load()
+    sc = _scene(rrt, "atrium", n_target=20000, tex_size=32)
+    w, h, depth = 96, 54, 8
+    hnd = sc.upload(0)
+    acc = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    m = sc.materials_array()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    done = 0
+    expect = np.zeros((h, w, 3), dtype=np.float32)
+    for n in (1, 2, 3):                              # three calls = samples 1, 2..3, 4..6 accumulated in place
+        o = rrt.make_options(w, h, n, depth, seed_mode=L.SEED_PER_SAMPLE, flags=L.FLAG_SUM | L.FLAG_ACCUM, sample_begin=done + 1)
+        L.check(lib.mipt_render_device(hnd, L.ptr(sc.camera.uniform), C.byref(o), C.c_void_p(acc.data_ptr()), None, stream, None), "render")
+        done += n
+        # running sum = previous sum + (this call's samples summed in order): the same f32 summation tree on the oracle side
+        part, _, _ = orc.render(sc.tris, sc.bvh_nodes, m, sc.textures, sc.camera.uniform, w, h, n, depth, seed_mode=1,
+                                sample_begin=done - n + 1, sum_only=1, want_rgba8=False)
+        expect = expect + part
+        assert np.array_equal(acc.cpu().numpy().view(np.uint32), expect.reshape(-1).view(np.uint32))
+    ref = expect
+    whole, _, _ = orc.render(sc.tris, sc.bvh_nodes, m, sc.textures, sc.camera.uniform, w, h, done, depth, seed_mode=1, sum_only=1, want_rgba8=False)
+    assert np.allclose(ref, whole, rtol=1e-6, atol=1e-6)     # vs one sequential pass: summation order only
+    out16 = torch.zeros(w * h * 4, dtype=torch.int16, device="cuda")
+    L.check(lib.mipt_postprocess_device(C.c_void_p(acc.data_ptr()), w * h, float(done), C.c_void_p(out16.data_ptr()), stream), "postprocess")
+    torch.cuda.synchronize()
+    got = out16.cpu().numpy().view(np.uint16).reshape(h, w, 4)
+    want = orc.postprocess(ref, divisor=float(done))
+    assert np.array_equal(got, want)
+    assert got[..., 3].min() == 65535 and 0 < got[..., :3].mean() < 65535
+    host.write_png_rgba16(str(tmp_path / "pp.png"), got)
+    sig = open(tmp_path / "pp.png", "rb").read(26)
+    assert sig[:8] == b"\x89PNG\r\n\x1a\n" and sig[24] == 16 and sig[25] == 6          # bit depth 16, colour type RGBA
+    # ACCUM without SUM, or through the host-buffer entry point, is rejected
+    o = rrt.make_options(w, h, 1, depth, flags=L.FLAG_ACCUM)
+    assert lib.mipt_render_device(hnd, L.ptr(sc.camera.uniform), C.byref(o), C.c_void_p(acc.data_ptr()), None, stream, None) == L.ERR_INVALID_ARG
