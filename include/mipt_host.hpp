@@ -1,0 +1,120 @@
+// mipt_host.hpp -- C++ host-side mirror of the reference's Renderer / Scene interface for the path-tracing hot path,
+// header-only over the C ABI of mipt.h.  The reference is Rust (no toolchain in this image), so the host side above the
+// ABI is C++: same type and member names, same argument meaning, same error behaviour --
+//   Renderer::create  = Renderer::new            (src/renderer.rs:14-48)  -> std::nullopt + the reference's log line
+//   Renderer::render                             (src/renderer.rs:50-85)  -> the Vec<u8> of the backend arm
+//   Scene::load / Scene::set_camera              (src/scene.rs:22-41)
+//   Camera::update_view                          (src/scene.rs:181-194)
+//   RendererBackend::{GPU, CPU} + MI355X         (src/renderer/backend.rs:6-10)
+#pragma once
+#include "mipt.h"
+
+#include <cstdio>
+#include <optional>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace mipt {
+
+inline void log_error(const std::string &m) { fprintf(stderr, "[ERROR] %s\n", m.c_str()); }   // src/log.rs:22-29
+
+enum class RendererBackend { GPU, CPU, MI355X };
+
+struct RendererOptions {                                   // src/renderer.rs:96-116 (same defaults)
+    size_t samples = 1;
+    size_t max_ray_depth = 6;
+    std::pair<size_t, size_t> output_image_dimensions{1920, 1080};
+    std::optional<std::string> output_image_path;
+    RendererBackend backend = RendererBackend::GPU;
+    bool is_realtime = true;
+    // MI355X arm only
+    uint32_t traversal = MIPT_TRAVERSAL_REFERENCE;
+    int device_id = 0;
+};
+
+struct Camera {                                            // src/scene.rs:169-195
+    float pitch = 0.0f, yaw = 0.0f;
+    float position[3] = {0.0f, 0.0f, 0.0f};
+    MiptCamera uniform{};                                  // look_at + position as uploaded (gpu.rs:480-486)
+    void update_view() { mipt_camera_from_pose(position, pitch, yaw, &uniform); }
+};
+
+struct Texture { uint32_t width = 0, height = 0; std::vector<uint8_t> pixel_data; };   // src/texture.rs:4-10
+
+class Scene {                                              // src/scene.rs:12-19
+  public:
+    std::vector<MiptTriangle> tris;
+    std::vector<std::pair<std::string, MiptMaterial>> materials;   // name -> Material, in material-id order
+    std::vector<Texture> textures;
+    std::vector<MiptNode> bvh_nodes;                       // scene.bvh.nodes
+    Camera camera;
+
+    static std::optional<Scene> load(const std::string &path) {    // src/scene.rs:22-36
+        MiptObj *obj = nullptr;
+        if (mipt_obj_load(path.c_str(), &obj) != MIPT_OK) { log_error(mipt_last_error()); return std::nullopt; }
+        MiptSceneDesc d{};
+        const char **names = nullptr;
+        mipt_obj_get(obj, &d, &names);
+        Scene s;
+        s.tris.assign(d.tris, d.tris + d.n_tris);
+        s.bvh_nodes.assign(d.nodes, d.nodes + d.n_nodes);
+        for (uint32_t i = 0; i < d.n_materials; i++) s.materials.emplace_back(names[i], d.materials[i]);
+        for (uint32_t i = 0; i < d.n_textures; i++) {
+            Texture t;
+            t.width = d.textures[i].width; t.height = d.textures[i].height;
+            t.pixel_data.assign(d.textures[i].rgba8, d.textures[i].rgba8 + (size_t)t.width * t.height * 4);
+            s.textures.push_back(std::move(t));
+        }
+        mipt_obj_free(obj);
+        return s;
+    }
+    void set_camera(const Camera &c) { camera = c; camera.update_view(); }   // src/scene.rs:38-41
+    void build_bvh(uint32_t threads = 0) {                 // BVH::build (src/bvh.rs:13-54)
+        bvh_nodes.resize(tris.empty() ? 1 : 2 * tris.size());
+        uint32_t n = 0;
+        if (mipt_bvh_build(tris.data(), (uint32_t)tris.size(), bvh_nodes.data(), (uint32_t)bvh_nodes.size(), &n, threads) != MIPT_OK) n = 0;
+        bvh_nodes.resize(n);
+    }
+};
+
+class Renderer {                                           // src/renderer.rs:8-85
+  public:
+    RendererOptions options;
+
+    static std::optional<Renderer> create(const RendererOptions &o) {      // Renderer::new, renderer.rs:14-48
+        if (o.output_image_dimensions.first == 0 || o.output_image_dimensions.second == 0) { log_error("Width and height must be greater than 0"); return std::nullopt; }
+        if (o.max_ray_depth == 0) { log_error("Max ray depth must be greater than 0"); return std::nullopt; }
+        if (o.samples == 0) { log_error("Sample count must be greater than 0"); return std::nullopt; }
+        if (!o.output_image_path && !o.is_realtime) { log_error("Output image path must be Some if realtime mode is disabled"); return std::nullopt; }
+        if (o.backend != RendererBackend::GPU && o.is_realtime) { log_error("Only the GPU backend is supported for realtime mode"); return std::nullopt; }
+        Renderer r;
+        r.options = o;
+        return r;
+    }
+
+    // The offline arm of Renderer::render (renderer.rs:55-64): returns the backend's Vec<u8> (w*h*4 RGBA8 for the
+    // MI355X arm, exactly what cpu::render_scene returns).  Empty on error (message logged).
+    std::vector<uint8_t> render(const Scene &scene) const {
+        if (options.backend != RendererBackend::MI355X) { log_error("this build only provides RendererBackend::MI355X"); return {}; }
+        std::vector<MiptMaterial> mats;
+        for (const auto &kv : scene.materials) mats.push_back(kv.second);
+        std::vector<MiptTexture> texs;
+        for (const Texture &t : scene.textures) texs.push_back({t.width, t.height, t.pixel_data.data()});
+        MiptSceneDesc d{scene.tris.data(), (uint32_t)scene.tris.size(), scene.bvh_nodes.data(), (uint32_t)scene.bvh_nodes.size(),
+                        mats.data(), (uint32_t)mats.size(), texs.data(), (uint32_t)texs.size()};
+        MiptScene *h = nullptr;
+        if (mipt_scene_create(&d, options.device_id, &h) != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        MiptOptions o{};
+        o.width = (uint32_t)options.output_image_dimensions.first; o.height = (uint32_t)options.output_image_dimensions.second;
+        o.samples = (uint32_t)options.samples; o.max_ray_depth = (uint32_t)options.max_ray_depth;
+        o.traversal = options.traversal; o.cull_margin = MIPT_CULL_MARGIN_SAFE;
+        std::vector<uint8_t> out((size_t)o.width * o.height * 4);
+        const int rc = mipt_render(h, &scene.camera.uniform, &o, nullptr, out.data(), nullptr);
+        mipt_scene_destroy(h);
+        if (rc != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        return out;
+    }
+};
+
+} // namespace mipt

@@ -1,0 +1,43 @@
+// C++ host-mirror checks.  `test_host cpu <cornell.obj>` needs no GPU; `test_host gpu <cornell.obj> <expected.rgba>` renders
+// BASELINE config 1 through Renderer::render and compares with the bytes the oracle produced.
+#include "mipt_host.hpp"
+
+#include <cstring>
+#include <fstream>
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    using namespace mipt;
+    CHECK(argc >= 3);
+    const std::string mode = argv[1], obj = argv[2];
+    // Renderer::new validation (renderer.rs:15-34)
+    RendererOptions o;
+    o.is_realtime = false; o.backend = RendererBackend::MI355X; o.output_image_path = "out.png";
+    { auto b = o; b.output_image_dimensions = {0, 5}; CHECK(!Renderer::create(b)); }
+    { auto b = o; b.max_ray_depth = 0; CHECK(!Renderer::create(b)); }
+    { auto b = o; b.samples = 0; CHECK(!Renderer::create(b)); }
+    { auto b = o; b.output_image_path.reset(); CHECK(!Renderer::create(b)); }
+    { auto b = o; b.is_realtime = true; CHECK(!Renderer::create(b)); }
+    { RendererOptions d; CHECK(d.samples == 1 && d.max_ray_depth == 6 && d.output_image_dimensions.first == 1920 && d.is_realtime); }
+    CHECK(!Scene::load("/nonexistent/scene.obj"));
+    auto scene = Scene::load(obj);
+    CHECK(scene && scene->tris.size() == 12 && scene->materials.size() == 4 && scene->materials[3].first == "light");
+    CHECK(scene->bvh_nodes.size() % 2 == 1 && scene->bvh_nodes.size() <= 23);
+    Camera cam;
+    cam.position[0] = 3.2f;
+    scene->set_camera(cam);
+    CHECK(scene->camera.uniform.look_at[2][0] == -1.0f && scene->camera.uniform.position.x == 3.2f);   // looks down -X
+    if (mode == "cpu") { printf("host mirror (cpu) ok\n"); return 0; }
+    CHECK(argc >= 4);
+    o.samples = 4; o.max_ray_depth = 64; o.output_image_dimensions = {256, 256};
+    auto r = Renderer::create(o);
+    CHECK(r);
+    const std::vector<uint8_t> px = r->render(*scene);
+    CHECK(px.size() == 256u * 256u * 4u);
+    std::ifstream f(argv[3], std::ios::binary);
+    std::vector<uint8_t> want((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    CHECK(want.size() == px.size() && memcmp(want.data(), px.data(), px.size()) == 0);
+    printf("host mirror (gpu) ok: config 1 RGBA8 identical to the oracle\n");
+    return 0;
+}
