@@ -1,0 +1,54 @@
+// ASan/UBSan build of the host-side C++ (BVH builder, OBJ/MTL loader, PNG decoder) -- GPU sanitizers are unavailable on
+// the pool, so memory safety of everything that parses untrusted files is checked on the CPU build:
+//   g++ -fsanitize=address,undefined bvh_build.cpp obj_loader.cpp png_decode.cpp sanitize_host.cpp
+// Feeds the loader valid files, truncated files and bit-flipped PNGs; builds BVHs over random soups.
+#include "mipt.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <string>
+#include <vector>
+
+static std::string g_err;
+void mipt_internal_set_error(const char *m) { g_err = m ? m : ""; }
+extern "C" void mipt_material_default(MiptMaterial *m) { memset(m, 0, sizeof *m); m->base_color = {0.8f, 0.8f, 0.8f}; m->base_color_tex_id = m->emission_tex_id = UINT32_MAX; }
+namespace mipt_png { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    const std::string dir = argv[1], png = argv[2];
+    // 1. loader on the fixtures written by the Python test
+    MiptObj *obj = nullptr;
+    int ok = 0, bad = 0;
+    for (const char *name : {"cornell.obj", "t.obj", "missing.obj", "neg.obj"}) {
+        if (mipt_obj_load((dir + "/" + name).c_str(), &obj) == MIPT_OK) { ok++; mipt_obj_free(obj); } else bad++;
+    }
+    // 2. PNG decoder under mutation: truncations and bit flips must fail cleanly or decode, never touch bad memory
+    std::ifstream f(png, std::ios::binary);
+    std::vector<uint8_t> good((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::mt19937 rng(7);
+    int decoded = 0, rejected = 0;
+    for (int it = 0; it < 3000; it++) {
+        std::vector<uint8_t> m = good;
+        if (it % 3 == 0) m.resize(rng() % (good.size() + 1));
+        else for (int k = 0; k < 1 + (int)(rng() % 6); k++) m[rng() % m.size()] ^= (uint8_t)(1u << (rng() % 8));
+        const std::string p = dir + "/mut.png";
+        { std::ofstream o(p, std::ios::binary); o.write((const char *)m.data(), (std::streamsize)m.size()); }
+        uint32_t w, h; std::vector<uint8_t> px; std::string err;
+        if (mipt_png::decode(p, &w, &h, &px, &err)) { decoded++; if (px.size() != (size_t)w * h * 4) return 3; } else rejected++;
+    }
+    // 3. BVH builder over random soups (threads on)
+    for (int n : {1, 2, 3, 17, 1000, 40000}) {
+        std::vector<MiptTriangle> t(n);
+        std::uniform_real_distribution<float> u(-1.f, 1.f);
+        for (auto &tri : t) { memset(&tri, 0, sizeof tri); for (auto &v : tri.vertices) v.position = {u(rng), u(rng), u(rng)}; }
+        std::vector<MiptNode> nodes(2 * n);
+        uint32_t cnt = 0;
+        if (mipt_bvh_build(t.data(), n, nodes.data(), 2 * n, &cnt, 4) != MIPT_OK || cnt == 0 || cnt > (uint32_t)(2 * n - 1 + (n == 1))) return 4;
+    }
+    printf("sanitize_host ok: loader %d ok / %d rejected, png %d decoded / %d rejected\n", ok, bad, decoded, rejected);
+    return 0;
+}
