@@ -218,6 +218,15 @@ def main():
     if rank == 0 and not args.no_parity:
         par = {}
         frame = d_frame.clone()
+        if world > 1:
+            # the all-gathered + de-interleaved frame must equal a frame rendered by this rank alone, bit for bit
+            solo = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+            opt1 = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM, trav, 0, 0, 1, cull_margin=L.CULL_MARGIN_SAFE)
+            L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt1), C.c_void_p(solo.data_ptr()), None,
+                                           C.c_void_p(stream.cuda_stream), None), "mipt_render_device")
+            torch.cuda.synchronize(dev)
+            par["gathered_frame_equals_single_gpu_frame"] = bool(torch.equal(frame.view(torch.int32), solo.view(torch.int32)))
+            del solo
         if world == 1 and args.traversal == "culled":
             ref_buf = torch.empty_like(d_local)
             render(traversal=L.TRAVERSAL_REFERENCE, out=ref_buf)
