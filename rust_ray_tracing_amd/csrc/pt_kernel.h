@@ -28,6 +28,8 @@ struct DevScene {
     const float4 *pairs;          // = geom: [pairs | tri_pos] live in ONE allocation so the traversal step can address either
     const float4 *tri_pos;        //   through one buffer descriptor with a 32-bit byte offset (tri_off_bytes = n_pairs * 64)
     uint32_t tri_off_bytes, geom_bytes;
+    const float4 *top;            // experiment: the first kTopPairs pairs in BFS order, child refs to cached pairs flagged (bit 30)
+    uint32_t n_top, top_pad;
     const float4 *tri_attr;
     const DevMaterial *mats;
     const uint32_t *texels;
@@ -56,6 +58,7 @@ struct DevParams {
     float samples_f;
     float cull_scale;                       // 1 + cull_margin
     uint32_t reverse_tiles;                 // hand out the tile list back to front (bottom rows first)
+    uint32_t lds_top;                       // experiment: serve the first kTopPairs pairs from LDS
     uint32_t service_num, service_den;      // run the service pass when need/live >= num/den
     float cam[12];                          // look_at columns 0..2 (xyz each), position
     float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
@@ -66,14 +69,16 @@ struct DevParams {
 constexpr int kStackLds = 16;               // per-lane traversal-stack entries held in LDS
 constexpr int kStackOvf = 48;               // further entries spilled to HBM (rarely touched)
 constexpr int kWavesPerBlock = 4;
+constexpr int kTopPairs = 127;              // tree-top pairs staged in LDS (7 levels, 8 KB per block) when MIPT_LDS_TOP is on
+constexpr uint32_t kTopFlag = 0x40000000u;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
 constexpr uint32_t kMaxTris = 1u << 25;     // stack-entry encoding: 25-bit triangle index
 constexpr uint32_t kMaxPairs = 1u << 24;    // 24-bit pair index in the child-ref form
 
 // Launchers (stream-ordered; no allocation, no synchronisation inside).
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull,
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool lds_top,
                         int grid_blocks, hipStream_t stream);
-int trace_blocks_per_cu(bool count, bool cull);     // occupancy query, cached
+int trace_blocks_per_cu(bool count, bool cull, bool lds_top);     // occupancy query
 hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t height,
                                uint32_t tile_world, float *hdr, hipStream_t stream);
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,

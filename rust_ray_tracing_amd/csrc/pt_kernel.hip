@@ -156,9 +156,14 @@ __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uin
 #ifndef MIPT_MIN_WAVES_PER_SIMD
 #define MIPT_MIN_WAVES_PER_SIMD 1
 #endif
-template <bool COUNT, bool CULL>
+template <bool COUNT, bool CULL, bool LDS_TOP>
 __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds][64];
+    __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
+    if (LDS_TOP) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kTopPairs * 4u; i += kBlockThreads) s_top[i] = sc.top[i];
+        __syncthreads();
+    }
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                 best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;
                 rd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 dir_safe = ray_safe(o, d);
-                sp = 0; pair = 0;
+                sp = 0; pair = LDS_TOP ? kTopFlag : 0u;
                 tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;   // root leaf (root_n > 0) or inner (empty range)
                 if (COUNT) c_rays++;
             }
@@ -340,8 +345,14 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
             const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * 48u) : (pair * 64u);
             unsigned long long g_ta = 0;
             if (COUNT && DIAG_STAMPS) g_ta = clock64();
-            const float4 r0 = ldg4(geom, voff), r1 = ldg4(geom, voff + 16u), r2 = ldg4(geom, voff + 32u),
-                         r3 = ldg4(geom, voff + 48u);                  // tri_pos is padded by one float4
+            float4 r0, r1, r2, r3;
+            if (LDS_TOP && !leaf && (pair & kTopFlag)) {                 // tree top: 64 B from LDS
+                const float4 *q = s_top + (pair & 0xffffu) * 4u;
+                r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3];
+            } else {
+                r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
+                r3 = ldg4(geom, voff + 48u);                             // tri_pos is padded by one float4
+            }
             // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
             // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
             asm volatile("" ::: "memory");
@@ -543,25 +554,32 @@ hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, flo
     return hipGetLastError();
 }
 
-template <bool COUNT, bool CULL>
+template <bool COUNT, bool CULL, bool TOP>
 static hipError_t launch_t(const DevScene &sc, const DevParams &pr, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
+    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL, TOP>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int grid, hipStream_t stream) {
-    if (count) return cull ? launch_t<true, true>(sc, pr, grid, stream) : launch_t<true, false>(sc, pr, grid, stream);
-    return cull ? launch_t<false, true>(sc, pr, grid, stream) : launch_t<false, false>(sc, pr, grid, stream);
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool top, int grid, hipStream_t stream) {
+    if (top) {
+        if (count) return cull ? launch_t<true, true, true>(sc, pr, grid, stream) : launch_t<true, false, true>(sc, pr, grid, stream);
+        return cull ? launch_t<false, true, true>(sc, pr, grid, stream) : launch_t<false, false, true>(sc, pr, grid, stream);
+    }
+    if (count) return cull ? launch_t<true, true, false>(sc, pr, grid, stream) : launch_t<true, false, false>(sc, pr, grid, stream);
+    return cull ? launch_t<false, true, false>(sc, pr, grid, stream) : launch_t<false, false, false>(sc, pr, grid, stream);
 }
 
-int trace_blocks_per_cu(bool count, bool cull) {
+template <bool COUNT, bool CULL, bool TOP>
+static int occ_t() {
     int n = 0;
-    hipError_t e;
-    if (count) e = cull ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<true, true>, kBlockThreads, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<true, false>, kBlockThreads, 0);
-    else e = cull ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<false, true>, kBlockThreads, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<false, false>, kBlockThreads, 0);
-    if (e != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, TOP>, kBlockThreads, 0) != hipSuccess) n = 1;
+    return n;
+}
+int trace_blocks_per_cu(bool count, bool cull, bool top) {
+    int n;
+    if (top) n = count ? (cull ? occ_t<true, true, true>() : occ_t<true, false, true>()) : (cull ? occ_t<false, true, true>() : occ_t<false, false, true>());
+    else n = count ? (cull ? occ_t<true, true, false>() : occ_t<true, false, false>()) : (cull ? occ_t<false, true, false>() : occ_t<false, false, false>());
+    if (n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
 }
