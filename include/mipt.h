@@ -92,6 +92,12 @@ enum MiptTraversal {
  * candidate in play; with 2^-7 the culled frame is bit-identical to the reference traversal on
  * every scene tested (tests/, bench.py re-checks it on each run) at +1 % node visits. */
 #define MIPT_CULL_MARGIN_SAFE 0.0078125f
+enum MiptShading {
+    MIPT_SHADING_CPU  = 0,        /* cpu/ray.rs:141-202: the rayon backend's trace (the parity target) */
+    MIPT_SHADING_WGPU = 1         /* rt_compute.wgsl:126-294: the wgpu shader's material model (GGX-VNDF specular, Schlick Fresnel,
+                                   * refraction + Beer absorption, alpha cut-out, Russian roulette from depth 4, normal maps,
+                                   * bilinear/repeat textures with 2.2 gamma); per-sample seeds always (rt_compute.wgsl:102) */
+};
 enum MiptFlags {
     MIPT_FLAG_COUNT  = 1u << 0,   /* counting build: fill rays / inner_steps / tri_tests / ... in MiptStats */
     MIPT_FLAG_PACKED = 1u << 1,   /* tile-sharded output is rank-packed (tile-major) instead of full-frame */
@@ -111,7 +117,8 @@ typedef struct {
     uint32_t tile_world;          /* ... of this many (0 or 1 = whole image); 8x8 tiles, round-robin */
     uint32_t sample_begin;        /* PER_SAMPLE: first sample number (0 -> 1, as gpu.rs:252 starts at 1) */
     float    cull_margin;         /* MIPT_TRAVERSAL_CULLED: relative margin (>= 0); see MIPT_CULL_MARGIN_SAFE */
-    uint32_t reserved[5];         /* must be 0 */
+    uint32_t shading;             /* MiptShading */
+    uint32_t reserved[4];         /* must be 0 */
 } MiptOptions;
 
 typedef struct {

@@ -25,7 +25,7 @@ class OrcOptions(C.Structure):
                 ("seed_mode", C.c_uint32), ("cull", C.c_uint32), ("libm", C.c_uint32), ("threads", C.c_uint32),
                 ("pix_begin", C.c_uint64), ("pix_end", C.c_uint64), ("pix_stride", C.c_uint32),
                 ("sample_begin", C.c_uint32), ("stack_cap", C.c_uint32), ("sum_only", C.c_uint32),
-                ("cull_margin", C.c_float)]
+                ("cull_margin", C.c_float), ("shading", C.c_uint32)]
 
 
 class OrcStats(C.Structure):
@@ -82,7 +82,7 @@ def load() -> C.CDLL:
     lib.orc_texture_color_at.restype = None
     lib.orc_pixel_screen.argtypes = [u32, u32, u32, C.POINTER(f32 * 2)]
     lib.orc_pixel_screen.restype = None
-    for name in ("orc_shim_cosf", "orc_shim_log10f"):
+    for name in ("orc_shim_cosf", "orc_shim_log10f", "orc_shim_sinf", "orc_shim_expf"):
         getattr(lib, name).argtypes = [f32]
         getattr(lib, name).restype = f32
     lib.orc_shim_powf.argtypes = [f32, f32]
@@ -132,7 +132,7 @@ def camera_from_pose(position, pitch, yaw) -> np.ndarray:
 
 def render(tris, nodes, materials, textures, camera, width, height, samples, max_ray_depth, *, seed_mode=0, cull=0,
            libm=LIBM_SHIM, threads=0, pix_begin=0, pix_end=0, pix_stride=0, sample_begin=0, sum_only=0, stack_cap=0,
-           cull_margin=0.0, want_rgba8=True):
+           cull_margin=0.0, shading=0, want_rgba8=True):
     """Returns (hdr [h,w,3] f32, rgba8 [h,w,4] u8 | None, stats dict).  Arrays may be any dtype of the right byte size."""
     tris = np.ascontiguousarray(tris)
     nodes = np.ascontiguousarray(nodes)
@@ -140,7 +140,7 @@ def render(tris, nodes, materials, textures, camera, width, height, samples, max
     camera = np.ascontiguousarray(camera)
     textures = [np.ascontiguousarray(t) for t in textures]
     opt = OrcOptions(width, height, samples, max_ray_depth, seed_mode, cull, libm, threads, pix_begin, pix_end, pix_stride,
-                     sample_begin, stack_cap, sum_only, cull_margin)
+                     sample_begin, stack_cap, sum_only, cull_margin, shading)
     hdr = np.zeros((height, width, 3), dtype=np.float32)
     rgba = np.zeros((height, width, 4), dtype=np.uint8) if want_rgba8 else None
     st = OrcStats()

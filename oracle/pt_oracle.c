@@ -162,9 +162,36 @@ float orc_shim_powf(float x, float y) {
     return (float)shim_exp(z);
 }
 
+float orc_shim_sinf(float x) {                     /* same reduction as orc_shim_cosf; sin(x) = {s, c, -s, -c}[k & 3] */
+    if (!(fabsf(x) <= 1048576.0f)) return x - x;
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_1T = 6.07710050650619224932e-11;
+    double xd = (double)x;
+    double kf = floor(xd * INV_PIO2 + 0.5);
+    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
+    long long k = (long long)kf;
+    double v;
+    switch (k & 3) {
+    case 0: v = shim_ksin(r); break;
+    case 1: v = shim_kcos(r); break;
+    case 2: v = -shim_ksin(r); break;
+    default: v = -shim_kcos(r); break;
+    }
+    return (float)v;
+}
+float orc_shim_expf(float x) {
+    if (x != x) return x;
+    if (x > 100.0f) return INFINITY;
+    if (x < -110.0f) return 0.0f;
+    return (float)shim_exp((double)x);
+}
+
 static inline float f_cos(float x, int libm)   { return libm == ORC_LIBM_HOST ? cosf(x) : orc_shim_cosf(x); }
 static inline float f_log10(float x, int libm) { return libm == ORC_LIBM_HOST ? log10f(x) : orc_shim_log10f(x); }
 static inline float f_pow(float x, float y, int libm) { return libm == ORC_LIBM_HOST ? powf(x, y) : orc_shim_powf(x, y); }
+static inline float f_sin(float x, int libm)   { return libm == ORC_LIBM_HOST ? sinf(x) : orc_shim_sinf(x); }
+static inline float f_exp(float x, int libm)   { return libm == ORC_LIBM_HOST ? expf(x) : orc_shim_expf(x); }
 
 /* ------------------------------------------------------------------------- */
 /* math.rs / vec3.rs / vec2.rs / mat4.rs subset                               */
@@ -447,6 +474,200 @@ static v3 trace(Ray *ray, uint32_t max_bounces, const SceneView *sc, uint32_t *r
     return v_divs(incoming_light, (float)curr_bounces);
 }
 
+/* ------------------------------------------------------------------------- */
+/* rt_compute.wgsl restatement -- the wgpu backend's material model            */
+/* (shading mode 1).  The reference has no CPU oracle for  */
+/* it and WGSL leaves much to the implementation (FMA fusion, the precision of */
+/* pow/exp/sin/cos/inverseSqrt, the bilinear filter's weights): this is ONE    */
+/* deterministic reading -- one rounded f32 op per operator, the shim for the  */
+/* transcendentals, exact f32 bilinear weights -- shared with the kernel.      */
+/* "parity unpinned" against a real GPU run.                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct { float x, y, z, w; } v4;
+static inline v3 w_normalize(v3 a) { return v_divs(a, v_length(a)); }          /* normalize(): v / length(v) */
+static inline float w_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+static v4 sample_texture(const OrcTexture *t, float u, float v, Ctx *cx) { /* rt_compute.wgsl:499-501; sampler gpu.rs:393-401: linear, repeat */
+    const int64_t W = t->width, H = t->height;
+    float uu = u * (float)W - 0.5f, vv = v * (float)H - 0.5f;
+    float fu = floorf(uu), fv = floorf(vv);
+    float a = uu - fu, b = vv - fv;
+    int64_t i0 = (fabsf(fu) < 1e9f) ? (int64_t)fu : 0, j0 = (fabsf(fv) < 1e9f) ? (int64_t)fv : 0;
+    if (!(a == a)) a = 0.0f;
+    if (!(b == b)) b = 0.0f;
+    int64_t i1 = i0 + 1, j1 = j0 + 1;
+    i0 = ((i0 % W) + W) % W; i1 = ((i1 % W) + W) % W; j0 = ((j0 % H) + H) % H; j1 = ((j1 % H) + H) % H;   /* AddressMode::Repeat */
+    const uint8_t *p00 = t->rgba8 + 4 * (i0 + j0 * W), *p10 = t->rgba8 + 4 * (i1 + j0 * W);
+    const uint8_t *p01 = t->rgba8 + 4 * (i0 + j1 * W), *p11 = t->rgba8 + 4 * (i1 + j1 * W);
+    float out[4];
+    for (int c = 0; c < 4; c++) {
+        float t00 = (float)p00[c] / 255.0f, t10 = (float)p10[c] / 255.0f, t01 = (float)p01[c] / 255.0f, t11 = (float)p11[c] / 255.0f;
+        float top = t00 * (1.0f - a) + t10 * a;
+        float bot = t01 * (1.0f - a) + t11 * a;
+        out[c] = top * (1.0f - b) + bot * b;
+    }
+    cx->s.texel_fetches++;
+    v4 r = {out[0], out[1], out[2], out[3]};
+    return r;
+}
+
+static void build_orthonormal_basis(v3 n, v3 *tangent, v3 *bitangent) {       /* rt_compute.wgsl:565-569 */
+    v3 up = (fabsf(n.z) < 0.9999999f) ? V3(0.0f, 0.0f, 1.0f) : V3(1.0f, 0.0f, 0.0f);
+    *tangent = w_normalize(v_cross(up, n));
+    *bitangent = v_cross(n, *tangent);
+}
+static inline v3 to_world(v3 t, v3 b, v3 n, v3 l) {                              /* tbn * local, :561-563 */
+    return V3((t.x * l.x + b.x * l.y) + n.x * l.z, (t.y * l.x + b.y * l.y) + n.y * l.z, (t.z * l.x + b.z * l.y) + n.z * l.z);
+}
+static inline v3 to_local(v3 t, v3 b, v3 n, v3 w) { return V3(v_dot(t, w), v_dot(b, w), v_dot(n, w)); } /* transpose(tbn) * world */
+
+static v3 sample_ggx_vndf(v3 ve, float ax, float ay, uint32_t *rng, int libm) {  /* rt_compute.wgsl:503-525 */
+    float u1 = orc_rand_f32(rng), u2 = orc_rand_f32(rng);
+    v3 Vh = w_normalize(V3(ax * ve.x, ay * ve.y, ve.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    v3 T1 = V3(1.0f, 0.0f, 0.0f);
+    if (lensq > 0.0f) { float inv = 1.0f / sqrtf(lensq); T1 = V3(-Vh.y * inv, Vh.x * inv, 0.0f * inv); }
+    v3 T2 = v_cross(Vh, T1);
+    float r = sqrtf(u1);
+    float phi = 2.0f * 3.1415926535f * u2;
+    float t1 = r * f_cos(phi, libm);
+    float t2 = r * f_sin(phi, libm);
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+    float k = sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    v3 Nh = v_add(v_add(v_muls(T1, t1), v_muls(T2, t2)), v_muls(Vh, k));
+    return w_normalize(V3(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
+}
+static v3 cosine_sample_hemisphere(uint32_t *rng, int libm) {                    /* rt_compute.wgsl:527-551 */
+    float ux = orc_rand_f32(rng), uy = orc_rand_f32(rng);
+    float ox = 2.0f * ux - 1.0f, oy = 2.0f * uy - 1.0f;
+    float dx, dy;
+    if (ox == 0.0f && oy == 0.0f) { dx = 0.0f; dy = 0.0f; }
+    else {
+        float theta, r;
+        if (fabsf(ox) > fabsf(oy)) { r = ox; theta = 0.7853981634f * (oy / ox); }
+        else { r = oy; theta = 1.5707963268f - 0.7853981634f * (ox / oy); }
+        dx = r * f_cos(theta, libm); dy = r * f_sin(theta, libm);
+    }
+    float z = sqrtf(fmaxf(0.0f, 1.0f - dx * dx - dy * dy));
+    return V3(dx, dy, z);
+}
+
+static v3 trace_wgsl(Ray *ray, uint32_t max_depth, const SceneView *sc, uint32_t *rng, Ctx *cx) { /* rt_compute.wgsl:126-229 */
+    const float EPSILON = 0.0001f;
+    const int libm = cx->libm;
+    v3 ray_color = V3(1.0f, 1.0f, 1.0f), incoming = V3(0.0f, 0.0f, 0.0f);
+    v3 prev_hit_point = ray->origin;
+    uint32_t depth = 0;
+    while (depth < max_depth) {
+        Hit hit; memset(&hit, 0, sizeof hit); hit.distance = ORC_MISS;
+        cx->cur_tri = UINT32_MAX;
+        traverse_bvh(ray, sc, &hit, cx);
+        if (!hit.has_hit) {                                                      /* :215-223 */
+            ray_color = v_mul(ray_color, V3(1.0f, 1.0f, 1.0f));
+            incoming = v_add(incoming, v_mul(V3(1.0f, 1.0f, 1.0f), ray_color));
+            break;
+        }
+        cx->s.hits++;
+        depth += 1;
+        /* intersect_tri differences (rt_compute.wgsl:318,328): point = fma(dir, t, origin); the normal is normalised */
+        v3 point = V3(fmaf(ray->direction.x, hit.distance, ray->origin.x), fmaf(ray->direction.y, hit.distance, ray->origin.y),
+                      fmaf(ray->direction.z, hit.distance, ray->origin.z));
+        v3 normal = w_normalize(hit.normal);
+        OrcMaterial m = sc->materials[hit.material_id];
+        /* set_surface_properties, :251-294 */
+        if (hit.front_face) m.ior = 1.0f / m.ior;
+        if (m.base_color_tex_id != UINT32_MAX) {
+            v4 t = sample_texture(&sc->textures[m.base_color_tex_id], hit.uvx, hit.uvy, cx);
+            m.base_color = V3(f_pow(t.x, 2.2f, libm), f_pow(t.y, 2.2f, libm), f_pow(t.z, 2.2f, libm));
+        }
+        if (m.transparency_tex_id != UINT32_MAX) m.transparency = sample_texture(&sc->textures[m.transparency_tex_id], hit.uvx, hit.uvy, cx).w;
+        if (m.roughness_tex_id != UINT32_MAX) m.roughness = sample_texture(&sc->textures[m.roughness_tex_id], hit.uvx, hit.uvy, cx).y;
+        if (m.metallic_tex_id != UINT32_MAX) m.metallic = sample_texture(&sc->textures[m.metallic_tex_id], hit.uvx, hit.uvy, cx).z;
+        if (m.emission_tex_id != UINT32_MAX) {
+            v4 t = sample_texture(&sc->textures[m.emission_tex_id], hit.uvx, hit.uvy, cx);
+            m.emission = V3(f_pow(t.x, 2.2f, libm), f_pow(t.y, 2.2f, libm), f_pow(t.z, 2.2f, libm));
+        }
+        v3 tangent, bitangent;
+        build_orthonormal_basis(normal, &tangent, &bitangent);
+        v3 tbn_n = normal;
+        if (m.normal_tex_id != UINT32_MAX) {
+            v4 t = sample_texture(&sc->textures[m.normal_tex_id], hit.uvx, hit.uvy, cx);
+            normal = w_normalize(to_world(tangent, bitangent, tbn_n, V3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f)));
+            build_orthonormal_basis(normal, &tangent, &bitangent);
+            tbn_n = normal;
+        }
+        float transmitted_distance = hit.distance;                               /* :143-148 */
+        if (hit.front_face) prev_hit_point = point;
+        else transmitted_distance = v_length(v_sub(point, prev_hit_point));
+        if (m.transparency < orc_rand_f32(rng)) {                                /* alpha cut-out, :150-153 */
+            ray->origin = v_add(point, v_muls(ray->direction, EPSILON));
+            continue;
+        }
+        float alpha = w_clamp(m.roughness * m.roughness, EPSILON, 1.0f);
+        v3 neg_dir = V3(-ray->direction.x, -ray->direction.y, -ray->direction.z);
+        v3 sampled_normal = to_world(tangent, bitangent, tbn_n, sample_ggx_vndf(to_local(tangent, bitangent, tbn_n, neg_dir), alpha, alpha, rng, libm));
+        /* pow(x, 2) and pow(x, 5) have integer literal exponents: read as repeated multiplication (what shader compilers emit;
+         * exp2(y*log2(x)) would be NaN for the negative base 1 - ior on back faces, which no render of the reference shows) */
+        float f0s = ((1.0f - m.ior) * (1.0f - m.ior)) / ((1.0f + m.ior) * (1.0f + m.ior));
+        v3 f0 = V3(f0s * (1.0f - m.metallic) + m.base_color.x * m.metallic, f0s * (1.0f - m.metallic) + m.base_color.y * m.metallic,
+                   f0s * (1.0f - m.metallic) + m.base_color.z * m.metallic);                   /* mix(f0, base_color, metallic) */
+        float p1 = 1.0f - v_dot(sampled_normal, neg_dir), p2 = p1 * p1;
+        float p5 = (p2 * p2) * p1;                                                             /* schlick_fresnel, :553-555 */
+        v3 fresnel = V3(f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5);
+        float two_ndi = 2.0f * v_dot(sampled_normal, ray->direction);                          /* reflect(I, N) = I - 2 dot(N, I) N */
+        v3 specular_dir = w_normalize(v_sub(ray->direction, v_muls(sampled_normal, two_ndi)));
+        v3 transmitted_dir;                                                                    /* refract(I, N, eta) */
+        {
+            float ndi = v_dot(sampled_normal, ray->direction);
+            float k = 1.0f - m.ior * m.ior * (1.0f - ndi * ndi);
+            v3 r = (k < 0.0f) ? V3(0.0f, 0.0f, 0.0f)
+                              : v_sub(v_muls(ray->direction, m.ior), v_muls(sampled_normal, m.ior * ndi + sqrtf(k)));
+            transmitted_dir = w_normalize(r);
+        }
+        v3 diffuse_dir = w_normalize(to_world(tangent, bitangent, tbn_n, cosine_sample_hemisphere(rng, libm)));
+        /* select_bsdf, :231-248 */
+        int specular = 0, transmitted = 0;
+        {
+            float r = orc_rand_f32(rng);
+            if (m.metallic > r) specular = 1;
+            else if (m.metallic + m.transmission > r) transmitted = 1;
+        }
+        v3 new_dir;
+        float fl = v_length(fresnel);
+        float r2 = orc_rand_f32(rng);
+        if (fl < r2 && !specular) {                                                            /* :167-186 */
+            ray_color = v_mul(ray_color, m.base_color);
+            if (transmitted) {
+                new_dir = transmitted_dir;
+                if (v_dot(new_dir, normal) > 0.0f) break;
+                v3 absorption = V3(1.0f, 1.0f, 1.0f);
+                if (!hit.front_face)
+                    absorption = V3(f_exp(-(1.0f - m.base_color.x) * transmitted_distance, libm), f_exp(-(1.0f - m.base_color.y) * transmitted_distance, libm),
+                                    f_exp(-(1.0f - m.base_color.z) * transmitted_distance, libm));
+                ray_color = v_mul(ray_color, absorption);
+            } else {
+                new_dir = diffuse_dir;
+            }
+        } else {                                                                               /* :187-196 */
+            if (specular) ray_color = v_mul(ray_color, fresnel);
+            new_dir = specular_dir;
+            if (v_dot(new_dir, normal) < 0.0f) break;
+        }
+        float rr = 1.0f;                                                                       /* Russian roulette, :198-207 */
+        if (depth >= 4) {
+            rr = fmaxf(ray_color.x, fmaxf(ray_color.z, ray_color.y));
+            if (rr < orc_rand_f32(rng)) break;
+        }
+        ray_color = v_divs(ray_color, rr);
+        incoming = v_add(incoming, v_mul(m.emission, ray_color));                              /* :209 */
+        ray->origin = v_add(point, v_muls(new_dir, EPSILON));
+        ray->direction = new_dir;
+    }
+    if (depth == 0) return incoming;
+    return v_divs(incoming, (float)depth);
+}
+
 float orc_intersect_node(const float o[3], const float d[3], const OrcNode *n) {
     Ray r = {V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2])};
     return intersect_node(&r, n, 0, ORC_MISS);
@@ -492,13 +713,14 @@ static void render_pixel(Job *job, uint64_t index, Ctx *cx) {
     float screen_y = (((float)y / (float)h) * 2.0f) - 1.0f;
     uint32_t s0 = o->sample_begin ? o->sample_begin : 1u;
     for (uint32_t s = 0; s < o->samples; s++) {                        /* cpu.rs:37 */
-        if (o->seed_mode == ORC_SEED_PER_SAMPLE)
+        if (o->seed_mode == ORC_SEED_PER_SAMPLE || o->shading == 1)
             rng = orc_sample_seed(s0 + s, x, (uint32_t)(index / w));   /* rt_compute.wgsl:102, global_id.y = row */
         float jx = (orc_rand_f32(&rng) * 2.0f - 1.0f) * 0.0005f;       /* cpu.rs:38-42 */
         float jy = (orc_rand_f32(&rng) * 2.0f - 1.0f) * 0.0005f;
         v3 dir = v_normalized(mat_mul_v3(job->cam->look_at, V3(-screen_x + jx, screen_y + jy, 1.0f))); /* cpu.rs:43-45 */
         Ray ray = {job->cam->position, dir};                           /* cpu.rs:46-50 */
-        final_color = v_add(final_color, trace(&ray, o->max_ray_depth, &job->sc, &rng, cx)); /* cpu.rs:52-57 */
+        final_color = v_add(final_color, o->shading == 1 ? trace_wgsl(&ray, o->max_ray_depth, &job->sc, &rng, cx)   /* rt_compute.wgsl:117 */
+                                                        : trace(&ray, o->max_ray_depth, &job->sc, &rng, cx)); /* cpu.rs:52-57 */
     }
     if (!o->sum_only) final_color = v_divs(final_color, (float)o->samples); /* cpu.rs:60 */
     if (job->hdr) {

@@ -81,6 +81,7 @@ typedef struct {
     uint32_t stack_cap;              /* traversal stack entries; 0 -> 64 (reference: 32, ray.rs:85) */
     uint32_t sum_only;               /* 1: hdr = sum over samples (no /samples), for sample-sharding */
     float    cull_margin;            /* cull=1: skip a child iff !(t_near < best*(1+margin)); 0 = the WGSL rule */
+    uint32_t shading;                /* 0 = cpu/ray.rs trace; 1 = rt_compute.wgsl trace (GGX/Fresnel/refraction/RR; per-sample seeds) */
 } OrcOptions;
 
 typedef struct {
@@ -140,6 +141,8 @@ void     orc_pixel_screen(uint32_t index, uint32_t w, uint32_t h, float out[2]);
 float    orc_shim_cosf(float x);
 float    orc_shim_log10f(float x);
 float    orc_shim_powf(float x, float y);
+float    orc_shim_sinf(float x);
+float    orc_shim_expf(float x);
 /* trace one explicit ray (ray.rs:141-202); returns radiance in out[3] */
 void     orc_trace_ray(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
                        const OrcMaterial *materials, uint32_t n_materials,

@@ -30,6 +30,7 @@ NO_TEXTURE = 0xFFFFFFFF
 
 SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
+SHADING_CPU, SHADING_WGPU = 0, 1
 FLAG_COUNT, FLAG_PACKED, FLAG_SUM, FLAG_ACCUM = 1, 2, 4, 8
 CULL_MARGIN_SAFE = 0.0078125  # MIPT_CULL_MARGIN_SAFE
 
@@ -51,7 +52,7 @@ class MiptOptions(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
                 ("max_ray_depth", C.c_uint32), ("seed_mode", C.c_uint32), ("traversal", C.c_uint32),
                 ("flags", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32),
-                ("sample_begin", C.c_uint32), ("cull_margin", C.c_float), ("reserved", C.c_uint32 * 5)]
+                ("sample_begin", C.c_uint32), ("cull_margin", C.c_float), ("shading", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class MiptStats(C.Structure):

@@ -22,7 +22,7 @@ static_assert(sizeof(MiptNode) == 32 && offsetof(MiptNode, first_tri_or_child) =
 static_assert(sizeof(MiptMaterial) == 80 && offsetof(MiptMaterial, ior) == 28 && offsetof(MiptMaterial, emission) == 32 &&
                   offsetof(MiptMaterial, roughness) == 44 && offsetof(MiptMaterial, base_color_tex_id) == 56, "Material");
 static_assert(sizeof(MiptCamera) == 80 && offsetof(MiptCamera, position) == 64, "UniformCamera");
-static_assert(sizeof(mipt::DevMaterial) == 64, "device records");
+static_assert(sizeof(mipt::DevMaterial) == 64 && sizeof(mipt::DevMaterialFull) == 128, "device records");
 
 namespace {
 
@@ -51,7 +51,7 @@ void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 struct MiptScene {
     int device = 0;
     mipt::DevScene dev{};
-    void *d_geom = nullptr, *d_top = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr,
+    void *d_geom = nullptr, *d_top = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_mats_full = nullptr,
          *d_texels = nullptr;
     // workspace
     mipt::DevStats *d_stats = nullptr;
@@ -71,7 +71,7 @@ namespace {
 void free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_geom, s->d_top, s->d_tri_attr, s->d_mats, s->d_texels,
+    void *ptrs[] = {s->d_geom, s->d_top, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels,
                     s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -214,6 +214,21 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
         if (m.emission_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.emission_tex_id]; d.emis_off = t.offset; d.emis_w = t.width; d.emis_h = t.height; }
         mats[i] = d;
     }
+    std::vector<mipt::DevMaterialFull> mats_full(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const MiptMaterial &m = desc->materials[i];
+        mipt::DevMaterialFull f{};
+        f.base[0] = m.base_color.x; f.base[1] = m.base_color.y; f.base[2] = m.base_color.z; f.transmission = m.transmission;
+        f.emission[0] = m.emission.x; f.emission[1] = m.emission.y; f.emission[2] = m.emission.z; f.ior = m.ior;
+        f.roughness = m.roughness; f.metallic = m.metallic; f.transparency = m.transparency;
+        const uint32_t ids[6] = {m.base_color_tex_id, m.transparency_tex_id, m.roughness_tex_id, m.metallic_tex_id, m.emission_tex_id, m.normal_tex_id};
+        for (int k = 0; k < 6; k++) {
+            if (ids[k] == UINT32_MAX) continue;
+            if (ids[k] >= desc->n_textures) return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
+            f.tex[k][0] = texs[ids[k]].offset; f.tex[k][1] = texs[ids[k]].width; f.tex[k][2] = texs[ids[k]].height;
+        }
+        mats_full[i] = f;
+    }
     std::vector<uint32_t> texels((size_t)n_texels);
     for (uint32_t i = 0; i < desc->n_textures; i++)
         memcpy(texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
@@ -268,7 +283,7 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
         }
     }
     if ((rc = upload(&s->d_top, top, 64)) || (rc = upload(&s->d_tri_attr, tri_attr)) ||
-        (rc = upload(&s->d_mats, mats, 64)) || (rc = upload(&s->d_texels, texels, 16))) {
+        (rc = upload(&s->d_mats, mats, 64)) || (rc = upload(&s->d_mats_full, mats_full, 128)) || (rc = upload(&s->d_texels, texels, 16))) {
         free_scene(s);
         return rc;
     }
@@ -289,6 +304,7 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
     s->dev.n_top = n_top;
     s->dev.tri_attr = (const float4 *)s->d_tri_attr;
     s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
+    s->dev.mats_full = (const mipt::DevMaterialFull *)s->d_mats_full;
     s->dev.texels = (const uint32_t *)s->d_texels;
     s->dev.n_pairs = n_pairs; s->dev.n_tris = desc->n_tris; s->dev.n_mats = desc->n_materials; s->dev.n_texs = desc->n_textures;
     // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0
@@ -325,6 +341,7 @@ static int validate_options(const MiptOptions *opt) {
     if (opt->tile_rank >= world) return fail(MIPT_ERR_INVALID_ARG, "tile_rank %u >= tile_world %u", opt->tile_rank, world);
     if ((opt->flags & MIPT_FLAG_SUM) && opt->seed_mode != MIPT_SEED_PER_SAMPLE && opt->sample_begin > 1)
         return fail(MIPT_ERR_INVALID_ARG, "sample_begin needs MIPT_SEED_PER_SAMPLE (the pixel stream cannot be entered mid-way)");
+    if (opt->shading > MIPT_SHADING_WGPU) return fail(MIPT_ERR_INVALID_ARG, "unknown shading mode %u", opt->shading);
     if (!(opt->cull_margin >= 0.0f) || opt->cull_margin > 1.0f) return fail(MIPT_ERR_INVALID_ARG, "cull_margin must be in [0, 1]");
     for (uint32_t r : opt->reserved)
         if (r) return fail(MIPT_ERR_INVALID_ARG, "reserved option fields must be 0");
@@ -349,7 +366,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
 
     mipt::DevParams pr{};
     pr.width = opt->width; pr.height = opt->height; pr.samples = opt->samples; pr.max_depth = opt->max_ray_depth;
-    pr.seed_mode = opt->seed_mode;
+    pr.seed_mode = opt->shading == MIPT_SHADING_WGPU ? (uint32_t)MIPT_SEED_PER_SAMPLE : opt->seed_mode;   // the shader seeds per sample
     pr.sample_begin = opt->sample_begin ? opt->sample_begin : 1u;
     pr.sum_only = (opt->flags & MIPT_FLAG_SUM) ? 1u : 0u;
     pr.packed = packed ? 1u : 0u;
@@ -377,7 +394,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
 
     const bool count = (opt->flags & MIPT_FLAG_COUNT) != 0;
     const bool cull = opt->traversal == MIPT_TRAVERSAL_CULLED;
-    const int occ = mipt::trace_blocks_per_cu(count, cull, pr.lds_top != 0 && scene->dev.n_top > 0);
+    const int occ = mipt::trace_blocks_per_cu(count, cull, pr.lds_top != 0 && scene->dev.n_top > 0 && opt->shading == 0, (int)opt->shading);
     int bpc = occ;
     // Small shards (multi-GPU tile split: fewer pixels than resident lanes) are bound by the longest per-pixel chain --
     // a pixel's samples are sequential on one RNG stream -- and each chain steps faster with fewer co-resident waves:
@@ -402,7 +419,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
 
     HIP_TRY(hipMemsetAsync(scene->d_stats, 0, sizeof(mipt::DevStats), stream));
     HIP_TRY(hipEventRecord(scene->ev0, stream));
-    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, pr.lds_top != 0 && scene->dev.n_top > 0, (int)grid, stream));
+    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, pr.lds_top != 0 && scene->dev.n_top > 0 && opt->shading == 0, (int)opt->shading, (int)grid, stream));
     HIP_TRY(hipEventRecord(scene->ev1, stream));
     if (d_rgba8) HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, (unsigned long long)opt->width * opt->height, 1.0f, d_rgba8, stream));
     mipt::DevStats hs;

@@ -78,6 +78,25 @@ __device__ __noinline__ float shim_cosf(float x) {
     }
     return (float)v;
 }
+__device__ __noinline__ float shim_sinf(float x) {           // same reduction as shim_cosf; sin(x) = {s, c, -s, -c}[k & 3]
+    if (!(fabsf(x) <= 1048576.0f)) return x - x;
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_1T = 6.07710050650619224932e-11;
+    double xd = (double)x;
+    double kf = floor(xd * INV_PIO2 + 0.5);
+    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
+    long long k = (long long)kf;
+    double s = shim_ksin(r), c = shim_kcos(r);
+    double v;
+    switch (k & 3) {
+    case 0: v = s; break;
+    case 1: v = c; break;
+    case 2: v = -s; break;
+    default: v = -c; break;
+    }
+    return (float)v;
+}
 __device__ __forceinline__ double shim_log_reduce(double xd, double &e_out) {
     const double SQRT2 = 1.41421356237309514547e+00;
     uint64_t b = (uint64_t)__double_as_longlong(xd);
@@ -135,6 +154,12 @@ __device__ __forceinline__ double shim_exp(double z) {
     long long k = (long long)kf;
     double scale = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
     return p * scale;
+}
+__device__ __noinline__ float shim_expf(float x) {
+    if (x != x) return x;
+    if (x > 100.0f) return __builtin_inff();
+    if (x < -110.0f) return 0.0f;
+    return (float)shim_exp((double)x);
 }
 __device__ __noinline__ float shim_powf(float x, float y) {
     const float INF = __builtin_inff();

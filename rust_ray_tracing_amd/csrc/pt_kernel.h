@@ -24,6 +24,16 @@ struct DevMaterial {
     uint32_t pad[4];
 };
 
+// 128 B: every Material field the wgpu backend's shader reads (rt_compute.wgsl:41-56) + the six textures' descriptors
+// {texel offset, width, height}; width == 0 = no texture.  Order: base, transparency, roughness, metallic, emission, normal.
+struct DevMaterialFull {
+    float base[3]; float transmission;
+    float emission[3]; float ior;
+    float roughness, metallic, transparency, pad0;
+    uint32_t tex[6][3];
+    uint32_t pad1[2];
+};
+
 struct DevScene {
     const float4 *pairs;          // = geom: [pairs | tri_pos] live in ONE allocation so the traversal step can address either
     const float4 *tri_pos;        //   through one buffer descriptor with a 32-bit byte offset (tri_off_bytes = n_pairs * 64)
@@ -32,6 +42,7 @@ struct DevScene {
     uint32_t n_top, top_pad;
     const float4 *tri_attr;
     const DevMaterial *mats;
+    const DevMaterialFull *mats_full;   // shading mode 1 (rt_compute.wgsl material model)
     const uint32_t *texels;
     uint32_t n_pairs, n_tris, n_mats, n_texs;
     uint32_t root_a, root_n;      // root node: leaf (root_n > 0: tris [root_a, root_a+root_n)) or inner (pair 0)
@@ -76,9 +87,9 @@ constexpr uint32_t kMaxTris = 1u << 25;     // stack-entry encoding: 25-bit tria
 constexpr uint32_t kMaxPairs = 1u << 24;    // 24-bit pair index in the child-ref form
 
 // Launchers (stream-ordered; no allocation, no synchronisation inside).
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool lds_top,
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool lds_top, int shading,
                         int grid_blocks, hipStream_t stream);
-int trace_blocks_per_cu(bool count, bool cull, bool lds_top);     // occupancy query
+int trace_blocks_per_cu(bool count, bool cull, bool lds_top, int shading);     // occupancy query
 hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t height,
                                uint32_t tile_world, float *hdr, hipStream_t stream);
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,

@@ -151,12 +151,189 @@ __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uin
     return mk(u8_over_255(px & 255u), u8_over_255((px >> 8) & 255u), u8_over_255((px >> 16) & 255u)); // vec3.rs:252-260
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Shading mode 1: the wgpu backend's material model (rt_compute.wgsl:126-294, 503-569), restated operator for operator
+// exactly as the CPU oracle restates it (one rounded f32 op per WGSL operator, transcendentals through the shim, exact
+// f32 bilinear weights).  SURVEY 8(f) rank 2.  Returns true when the path ends (`break` in the WGSL loop).
+// ---------------------------------------------------------------------------------------------------------------
+struct V4 { float x, y, z, w; };
+__device__ __forceinline__ float w_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ __noinline__ V4 sample_texture_bilinear(const uint32_t *texels, uint32_t offset, uint32_t width, uint32_t height, float u, float v) {
+    const long long W = width, H = height;                                   // textureSampleLevel: linear, repeat (gpu.rs:393-401)
+    const float uu = u * (float)W - 0.5f, vv = v * (float)H - 0.5f;
+    const float fu = floorf(uu), fv = floorf(vv);
+    float a = uu - fu, b = vv - fv;
+    long long i0 = (fabsf(fu) < 1e9f) ? (long long)fu : 0, j0 = (fabsf(fv) < 1e9f) ? (long long)fv : 0;
+    if (!(a == a)) a = 0.0f;
+    if (!(b == b)) b = 0.0f;
+    long long i1 = i0 + 1, j1 = j0 + 1;
+    i0 = ((i0 % W) + W) % W; i1 = ((i1 % W) + W) % W; j0 = ((j0 % H) + H) % H; j1 = ((j1 % H) + H) % H;
+    const uint32_t p00 = texels[(size_t)offset + (size_t)(i0 + j0 * W)], p10 = texels[(size_t)offset + (size_t)(i1 + j0 * W)];
+    const uint32_t p01 = texels[(size_t)offset + (size_t)(i0 + j1 * W)], p11 = texels[(size_t)offset + (size_t)(i1 + j1 * W)];
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float t00 = u8_over_255((p00 >> (8 * c)) & 255u), t10 = u8_over_255((p10 >> (8 * c)) & 255u);
+        const float t01 = u8_over_255((p01 >> (8 * c)) & 255u), t11 = u8_over_255((p11 >> (8 * c)) & 255u);
+        const float top = t00 * (1.0f - a) + t10 * a;
+        const float bot = t01 * (1.0f - a) + t11 * a;
+        out[c] = top * (1.0f - b) + bot * b;
+    }
+    V4 r; r.x = out[0]; r.y = out[1]; r.z = out[2]; r.w = out[3];
+    return r;
+}
+__device__ __forceinline__ void build_onb(V3 n, V3 &tangent, V3 &bitangent) {                  // rt_compute.wgsl:565-569
+    const V3 up = (fabsf(n.z) < 0.9999999f) ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);
+    tangent = normalized(cross(up, n));
+    bitangent = cross(n, tangent);
+}
+__device__ __forceinline__ V3 to_world(V3 t, V3 b, V3 n, V3 l) {
+    return mk((t.x * l.x + b.x * l.y) + n.x * l.z, (t.y * l.x + b.y * l.y) + n.y * l.z, (t.z * l.x + b.z * l.y) + n.z * l.z);
+}
+__device__ __forceinline__ V3 to_local(V3 t, V3 b, V3 n, V3 w) { return mk(dot(t, w), dot(b, w), dot(n, w)); }
+
+__device__ __forceinline__ V3 sample_ggx_vndf(V3 ve, float ax, float ay, uint32_t &rng) {      // rt_compute.wgsl:503-525
+    const float u1 = rand_f32(rng), u2 = rand_f32(rng);
+    const V3 Vh = normalized(mk(ax * ve.x, ay * ve.y, ve.z));
+    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    V3 T1 = mk(1.0f, 0.0f, 0.0f);
+    if (lensq > 0.0f) { const float inv = 1.0f / __builtin_sqrtf(lensq); T1 = mk(-Vh.y * inv, Vh.x * inv, 0.0f * inv); }
+    const V3 T2 = cross(Vh, T1);
+    const float r = __builtin_sqrtf(u1);
+    const float phi = 2.0f * 3.1415926535f * u2;
+    const float t1 = r * shim_cosf(phi);
+    float t2 = r * shim_sinf(phi);
+    const float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * __builtin_sqrtf(1.0f - t1 * t1) + s * t2;
+    const float k = __builtin_sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    const V3 Nh = (T1 * t1 + T2 * t2) + Vh * k;
+    return normalized(mk(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
+}
+__device__ __forceinline__ V3 cosine_sample_hemisphere(uint32_t &rng) {                          // rt_compute.wgsl:527-551
+    const float ux = rand_f32(rng), uy = rand_f32(rng);
+    const float ox = 2.0f * ux - 1.0f, oy = 2.0f * uy - 1.0f;
+    float dx, dy;
+    if (ox == 0.0f && oy == 0.0f) { dx = 0.0f; dy = 0.0f; }
+    else {
+        float theta, r;
+        if (fabsf(ox) > fabsf(oy)) { r = ox; theta = 0.7853981634f * (oy / ox); }
+        else { r = oy; theta = 1.5707963268f - 0.7853981634f * (ox / oy); }
+        dx = r * shim_cosf(theta); dy = r * shim_sinf(theta);
+    }
+    const float z = __builtin_sqrtf(fmaxf(0.0f, 1.0f - dx * dx - dy * dy));
+    return mk(dx, dy, z);
+}
+
+__device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ray_color, V3 &incoming, V3 &prev_hit_point,
+                                        uint32_t depth, uint32_t &rng, float t, float u, float v, uint32_t best_tri, uint32_t &n_tex) {
+    const float EPSILON = 0.0001f;
+    const uint32_t tri = best_tri & ~kFrontBit;
+    const bool front_face = (best_tri & kFrontBit) != 0u;
+    const float4 a0 = sc.tri_attr[(size_t)tri * 4 + 0], a1 = sc.tri_attr[(size_t)tri * 4 + 1];
+    const float4 a2 = sc.tri_attr[(size_t)tri * 4 + 2], a3 = sc.tri_attr[(size_t)tri * 4 + 3];
+    const float w = 1.0f - u - v;
+    V3 raw_n = mk(a0.x, a0.y, a0.z) * w + mk(a0.w, a1.x, a1.y) * u + mk(a1.z, a1.w, a2.x) * v;
+    if (!front_face) raw_n = mk(-raw_n.x, -raw_n.y, -raw_n.z);
+    V3 normal = normalized(raw_n);                                                     // rt_compute.wgsl:328
+    const float uvx = ((a2.y * w) + (a2.w * u)) + (a3.y * v);
+    const float uvy = ((a2.z * w) + (a3.x * u)) + (a3.z * v);
+    const V3 point = mk(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z));   // :318 fma
+    const DevMaterialFull m = sc.mats_full[__float_as_uint(a3.w)];
+    V3 base = mk(m.base[0], m.base[1], m.base[2]), emission = mk(m.emission[0], m.emission[1], m.emission[2]);
+    float ior = m.ior, transparency = m.transparency, roughness = m.roughness, metallic = m.metallic;
+    if (front_face) ior = 1.0f / ior;                                                  // set_surface_properties, :251-294
+    if (m.tex[0][1] != 0u) {
+        const V4 tx = sample_texture_bilinear(sc.texels, m.tex[0][0], m.tex[0][1], m.tex[0][2], uvx, uvy); n_tex++;
+        base = mk(shim_powf(tx.x, 2.2f), shim_powf(tx.y, 2.2f), shim_powf(tx.z, 2.2f));
+    }
+    if (m.tex[1][1] != 0u) { transparency = sample_texture_bilinear(sc.texels, m.tex[1][0], m.tex[1][1], m.tex[1][2], uvx, uvy).w; n_tex++; }
+    if (m.tex[2][1] != 0u) { roughness = sample_texture_bilinear(sc.texels, m.tex[2][0], m.tex[2][1], m.tex[2][2], uvx, uvy).y; n_tex++; }
+    if (m.tex[3][1] != 0u) { metallic = sample_texture_bilinear(sc.texels, m.tex[3][0], m.tex[3][1], m.tex[3][2], uvx, uvy).z; n_tex++; }
+    if (m.tex[4][1] != 0u) {
+        const V4 tx = sample_texture_bilinear(sc.texels, m.tex[4][0], m.tex[4][1], m.tex[4][2], uvx, uvy); n_tex++;
+        emission = mk(shim_powf(tx.x, 2.2f), shim_powf(tx.y, 2.2f), shim_powf(tx.z, 2.2f));
+    }
+    V3 tangent, bitangent;
+    build_onb(normal, tangent, bitangent);
+    V3 tbn_n = normal;
+    if (m.tex[5][1] != 0u) {
+        const V4 tx = sample_texture_bilinear(sc.texels, m.tex[5][0], m.tex[5][1], m.tex[5][2], uvx, uvy); n_tex++;
+        normal = normalized(to_world(tangent, bitangent, tbn_n, mk(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f)));
+        build_onb(normal, tangent, bitangent);
+        tbn_n = normal;
+    }
+    float transmitted_distance = t;                                                    // :143-148
+    if (front_face) prev_hit_point = point;
+    else transmitted_distance = length(point - prev_hit_point);
+    if (transparency < rand_f32(rng)) {                                                // alpha cut-out, :150-153
+        o = point + d * EPSILON;
+        return false;
+    }
+    const float alpha = w_clamp(roughness * roughness, EPSILON, 1.0f);
+    const V3 neg_dir = mk(-d.x, -d.y, -d.z);
+    const V3 sampled_normal = to_world(tangent, bitangent, tbn_n, sample_ggx_vndf(to_local(tangent, bitangent, tbn_n, neg_dir), alpha, alpha, rng));
+    // integer literal exponents = repeated multiplication (same reading as the CPU oracle)
+    const float f0s = ((1.0f - ior) * (1.0f - ior)) / ((1.0f + ior) * (1.0f + ior));
+    const V3 f0 = mk(f0s * (1.0f - metallic) + base.x * metallic, f0s * (1.0f - metallic) + base.y * metallic, f0s * (1.0f - metallic) + base.z * metallic);
+    const float p1 = 1.0f - dot(sampled_normal, neg_dir), p2 = p1 * p1;
+    const float p5 = (p2 * p2) * p1;                                                   // schlick_fresnel, :553-555
+    const V3 fresnel = mk(f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5);
+    const float two_ndi = 2.0f * dot(sampled_normal, d);
+    const V3 specular_dir = normalized(d - sampled_normal * two_ndi);                  // reflect
+    V3 transmitted_dir;
+    {
+        const float ndi = dot(sampled_normal, d);                                      // refract
+        const float k = 1.0f - ior * ior * (1.0f - ndi * ndi);
+        const V3 r = (k < 0.0f) ? mk(0.0f, 0.0f, 0.0f) : (d * ior - sampled_normal * (ior * ndi + __builtin_sqrtf(k)));
+        transmitted_dir = normalized(r);
+    }
+    const V3 diffuse_dir = normalized(to_world(tangent, bitangent, tbn_n, cosine_sample_hemisphere(rng)));
+    bool specular = false, transmitted = false;                                        // select_bsdf, :231-248
+    {
+        const float r = rand_f32(rng);
+        if (metallic > r) specular = true;
+        else if (metallic + m.transmission > r) transmitted = true;
+    }
+    V3 new_dir;
+    const float fl = length(fresnel);
+    const float r2 = rand_f32(rng);
+    if (fl < r2 && !specular) {                                                        // :167-186
+        ray_color = ray_color * base;
+        if (transmitted) {
+            new_dir = transmitted_dir;
+            if (dot(new_dir, normal) > 0.0f) return true;
+            V3 absorption = mk(1.0f, 1.0f, 1.0f);
+            if (!front_face)
+                absorption = mk(shim_expf(-(1.0f - base.x) * transmitted_distance), shim_expf(-(1.0f - base.y) * transmitted_distance),
+                                shim_expf(-(1.0f - base.z) * transmitted_distance));
+            ray_color = ray_color * absorption;
+        } else {
+            new_dir = diffuse_dir;
+        }
+    } else {                                                                           // :187-196
+        if (specular) ray_color = ray_color * fresnel;
+        new_dir = specular_dir;
+        if (dot(new_dir, normal) < 0.0f) return true;
+    }
+    float rr = 1.0f;                                                                   // Russian roulette, :198-207
+    if (depth >= 4u) {
+        rr = fmaxf(ray_color.x, fmaxf(ray_color.z, ray_color.y));
+        if (rr < rand_f32(rng)) return true;
+    }
+    ray_color = ray_color / rr;
+    incoming = incoming + emission * ray_color;                                        // :209
+    o = point + new_dir * EPSILON;
+    d = new_dir;
+    return false;
+}
+
 } // namespace
 
 #ifndef MIPT_MIN_WAVES_PER_SIMD
 #define MIPT_MIN_WAVES_PER_SIMD 1
 #endif
-template <bool COUNT, bool CULL, bool LDS_TOP>
+template <bool COUNT, bool CULL, bool LDS_TOP, int SHADING>
 __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds][64];
     __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
@@ -178,6 +355,7 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
     bool dir_safe = false;
     V3 ray_color = mk(1, 1, 1), incoming = mk(0, 0, 0), emitted = mk(0, 0, 0), final_color = mk(0, 0, 0);
     uint32_t rng = 0, pix = 0, slot = 0, sample = 0, bounces = 0;
+    V3 prev_hit_point = mk(0, 0, 0);                       // SHADING == 1 only (rt_compute.wgsl:130)
     float screen_x = 0, screen_y = 0;
     // ---- per-lane traversal state ----
     float best_t = kMiss, best_u = 0, best_v = 0;
@@ -201,7 +379,17 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
             bool start_ray = false;
             if (state == ST_S) {
                 bool path_done;
-                if (best_tri != kNoTri) {                                          // ray.rs:152-183
+                if (SHADING == 1 && best_tri != kNoTri) {                          // rt_compute.wgsl:137-213
+                    bounces += 1;                                                  // curr_ray_depth += 1 (before the cut-out test)
+                    uint32_t n_tex = 0;
+                    const bool ended = shade_wgsl(sc, o, d, ray_color, incoming, prev_hit_point, bounces, rng, best_t, best_u, best_v, best_tri, n_tex);
+                    if (COUNT) { c_hits++; c_tex += n_tex; }
+                    path_done = ended || !(bounces < pr.max_depth);
+                } else if (SHADING == 1) {                                         // miss, rt_compute.wgsl:215-223
+                    ray_color = ray_color * mk(1.0f, 1.0f, 1.0f);
+                    incoming = incoming + mk(1.0f, 1.0f, 1.0f) * ray_color;
+                    path_done = true;
+                } else if (best_tri != kNoTri) {                                   // ray.rs:152-183
                     const uint32_t tri = best_tri & ~kFrontBit;
                     const float4 a0 = sc.tri_attr[(size_t)tri * 4 + 0], a1 = sc.tri_attr[(size_t)tri * 4 + 1];
                     const float4 a2 = sc.tri_attr[(size_t)tri * 4 + 2], a3 = sc.tri_attr[(size_t)tri * 4 + 3];
@@ -298,7 +486,7 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
             }
             // ---- camera ray (cpu.rs:37-50) ----
             if (state == ST_G) {
-                if (pr.seed_mode != 0u) {                                             // rt_compute.wgsl:102
+                if (SHADING == 1 || pr.seed_mode != 0u) {                             // rt_compute.wgsl:102
                     const uint32_t px = pix % pr.width, py = pix / pr.width;
                     rng = (pr.sample_begin + sample) * 6023u + (757283u * px + 872653746u * py);
                 }
@@ -315,6 +503,7 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                 incoming = mk(0.0f, 0.0f, 0.0f);
                 emitted = mk(0.0f, 0.0f, 0.0f);
                 bounces = 0;
+                if (SHADING == 1) prev_hit_point = o;
                 state = ST_T;
                 start_ray = true;
             }
@@ -554,31 +743,38 @@ hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, flo
     return hipGetLastError();
 }
 
-template <bool COUNT, bool CULL, bool TOP>
+template <bool COUNT, bool CULL, bool TOP, int SHADING>
 static hipError_t launch_t(const DevScene &sc, const DevParams &pr, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL, TOP>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
+    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL, TOP, SHADING>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
     return hipGetLastError();
 }
-
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool top, int grid, hipStream_t stream) {
-    if (top) {
-        if (count) return cull ? launch_t<true, true, true>(sc, pr, grid, stream) : launch_t<true, false, true>(sc, pr, grid, stream);
-        return cull ? launch_t<false, true, true>(sc, pr, grid, stream) : launch_t<false, false, true>(sc, pr, grid, stream);
-    }
-    if (count) return cull ? launch_t<true, true, false>(sc, pr, grid, stream) : launch_t<true, false, false>(sc, pr, grid, stream);
-    return cull ? launch_t<false, true, false>(sc, pr, grid, stream) : launch_t<false, false, false>(sc, pr, grid, stream);
-}
-
-template <bool COUNT, bool CULL, bool TOP>
+template <bool COUNT, bool CULL, bool TOP, int SHADING>
 static int occ_t() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, TOP>, kBlockThreads, 0) != hipSuccess) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, TOP, SHADING>, kBlockThreads, 0) != hipSuccess) n = 1;
     return n;
 }
-int trace_blocks_per_cu(bool count, bool cull, bool top) {
-    int n;
-    if (top) n = count ? (cull ? occ_t<true, true, true>() : occ_t<true, false, true>()) : (cull ? occ_t<false, true, true>() : occ_t<false, false, true>());
-    else n = count ? (cull ? occ_t<true, true, false>() : occ_t<true, false, false>()) : (cull ? occ_t<false, true, false>() : occ_t<false, false, false>());
+// instantiations: CPU-backend shading x {count, cull, lds_top}; wgpu-shader shading x {count, cull}
+#define MIPT_DISPATCH(FN, ...)                                                                                          \
+    do {                                                                                                                \
+        if (shading == 1) {                                                                                             \
+            if (count) return cull ? FN<true, true, false, 1>(__VA_ARGS__) : FN<true, false, false, 1>(__VA_ARGS__);    \
+            return cull ? FN<false, true, false, 1>(__VA_ARGS__) : FN<false, false, false, 1>(__VA_ARGS__);             \
+        }                                                                                                               \
+        if (top) {                                                                                                      \
+            if (count) return cull ? FN<true, true, true, 0>(__VA_ARGS__) : FN<true, false, true, 0>(__VA_ARGS__);      \
+            return cull ? FN<false, true, true, 0>(__VA_ARGS__) : FN<false, false, true, 0>(__VA_ARGS__);               \
+        }                                                                                                               \
+        if (count) return cull ? FN<true, true, false, 0>(__VA_ARGS__) : FN<true, false, false, 0>(__VA_ARGS__);        \
+        return cull ? FN<false, true, false, 0>(__VA_ARGS__) : FN<false, false, false, 0>(__VA_ARGS__);                 \
+    } while (0)
+
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool top, int shading, int grid, hipStream_t stream) {
+    MIPT_DISPATCH(launch_t, sc, pr, grid, stream);
+}
+static int occ_dispatch(bool count, bool cull, bool top, int shading) { MIPT_DISPATCH(occ_t); }
+int trace_blocks_per_cu(bool count, bool cull, bool top, int shading) {
+    int n = occ_dispatch(count, cull, top, shading);
     if (n < 1) n = 1;
     if (n > 8) n = 8;
     return n;

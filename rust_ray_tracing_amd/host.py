@@ -52,6 +52,7 @@ class RendererOptions:  # renderer.rs:96-116
     seed_mode: int = L.SEED_PIXEL_STREAM
     traversal: int = L.TRAVERSAL_REFERENCE
     cull_margin: float = L.CULL_MARGIN_SAFE
+    shading: int = L.SHADING_CPU          # SHADING_WGPU: the wgpu shader's material model (rt_compute.wgsl)
     device_id: int = 0
 
 
@@ -179,12 +180,13 @@ class Scene:  # scene.rs:12-19
 
 
 def make_options(width, height, samples, max_ray_depth, seed_mode=L.SEED_PIXEL_STREAM, traversal=L.TRAVERSAL_REFERENCE,
-                 flags=0, tile_rank=0, tile_world=0, sample_begin=0, cull_margin=L.CULL_MARGIN_SAFE) -> L.MiptOptions:
+                 flags=0, tile_rank=0, tile_world=0, sample_begin=0, cull_margin=L.CULL_MARGIN_SAFE, shading=0) -> L.MiptOptions:
     o = L.MiptOptions()
     o.width, o.height, o.samples, o.max_ray_depth = width, height, samples, max_ray_depth
     o.seed_mode, o.traversal, o.flags = seed_mode, traversal, flags
     o.tile_rank, o.tile_world, o.sample_begin = tile_rank, tile_world, sample_begin
     o.cull_margin = cull_margin
+    o.shading = shading
     return o
 
 
@@ -221,7 +223,7 @@ class Renderer:  # renderer.rs:8-85
             raise NotImplementedError(f"backend {o.backend.name} is not part of this build; use RendererBackend.MI355X")
         w, h = o.output_image_dimensions
         handle = scene.upload(o.device_id)
-        opt = make_options(w, h, o.samples, o.max_ray_depth, o.seed_mode, o.traversal, flags, cull_margin=o.cull_margin)
+        opt = make_options(w, h, o.samples, o.max_ray_depth, o.seed_mode, o.traversal, flags, cull_margin=o.cull_margin, shading=o.shading)
         hdr = np.zeros((h, w, 3), dtype=np.float32) if want_hdr else None
         rgba = np.zeros((h, w, 4), dtype=np.uint8) if want_rgba8 else None
         st = L.MiptStats()
