@@ -205,6 +205,12 @@ int  mipt_obj_load(const char *path, MiptObj **out);
 int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
 void mipt_obj_free(MiptObj *obj);
 
+/* The same build on the GPU (level-synchronous binned SAH with the partition's closed-form permutation); identical output
+ * (sign of zero in a bound aside).  Uploads `tris`, downloads the reordered triangles and the nodes; build_ms_out (may be
+ * NULL) receives the device time of the build itself without the transfers. */
+int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
+                          uint32_t *n_nodes_out, int device_id, double *build_ms_out);
+
 /* Camera::update_view + Mat4f::look_at (src/scene.rs:181-194, src/math/mat4.rs:25-44). */
 int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg, MiptCamera *out);
 

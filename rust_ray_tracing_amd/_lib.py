@@ -70,7 +70,7 @@ class MiptStats(C.Structure):
 # every symbol include/mipt.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "mipt_scene_create", "mipt_scene_destroy", "mipt_render", "mipt_render_device",
-    "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_postprocess_device", "mipt_bvh_build",
+    "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_postprocess_device", "mipt_bvh_build", "mipt_bvh_build_device",
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
     "mipt_device_count", "mipt_debug_eval", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
 ]
@@ -112,6 +112,8 @@ def load() -> C.CDLL:
     lib.mipt_postprocess_device.restype = C.c_int
     lib.mipt_bvh_build.argtypes = [vp, u32, vp, u32, C.POINTER(u32), u32]
     lib.mipt_bvh_build.restype = C.c_int
+    lib.mipt_bvh_build_device.argtypes = [vp, u32, vp, u32, C.POINTER(u32), C.c_int, C.POINTER(C.c_double)]
+    lib.mipt_bvh_build_device.restype = C.c_int
     lib.mipt_camera_from_pose.argtypes = [C.POINTER(f32 * 3), f32, f32, vp]
     lib.mipt_camera_from_pose.restype = C.c_int
     lib.mipt_material_default.argtypes = [vp]

@@ -1,0 +1,402 @@
+// bvh_build_device.hip -- BVH::build (reference src/bvh.rs:13-161) on the GPU, emitting the IDENTICAL node array and
+// triangle order as the host restatement (bvh_build.cpp) and the reference.  SURVEY 8(f) rank 4.
+//
+// Level-synchronous: one 256-thread workgroup per node of the current level.
+//   1. centroid range per axis (block reduction; f32 min/max are exact and order-independent)
+//   2. "first plane the centroid is below" binning with the reference's own plane values and `<` comparisons
+//      (bvh.rs:82-84,147), per-bin boxes and counts through LDS integer atomics on order-preserving keys
+//   3. thread 0 evaluates the 21 candidate costs with the reference's f32 expression (bvh.rs:150-160, incl. the
+//      0*inf = NaN -> f32::MAX rule) and picks the first strictly lower one, axis-major / plane-minor (bvh.rs:86)
+//   4. the partition loop (bvh.rs:99-108) is sequential in the reference; its result is a fixed permutation with a closed
+//      form (derived and brute-forced in tests/test_bvh.py::test_partition_closed_form):
+//         k = #(c < pos);  holes h_0<h_1<.. = positions < k holding a ">=" element;  t_0>t_1>.. = positions >= k holding a "<"
+//         "<" at p < k stays;  h_m -> t_(m-1) - 1 (t_-1 = n);  t_m -> h_m;
+//         ">=" at p >= k: p > t_last -> p-1;  p == k -> t_last - 1;  else p-1   (t_last = n when there is no hole)
+//      computed with block-wide scans, written out of place (ping-pong proxy buffers).
+//   5. children appended in pairs; a final pass renumbers the breadth-first tree into the reference's depth-first order
+//      desc(X) = [A, B] ++ desc(A) ++ desc(B) (bvh.rs:131-135) and gathers the 112-byte triangles.
+#include "../../include/mipt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+void mipt_internal_set_error(const char *msg);
+
+namespace {
+
+constexpr int kT = 256;
+constexpr float F32_MAX = FLT_MAX;
+constexpr uint32_t kNone = 0xffffffffu;
+
+struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
+struct BNode {
+    float lo[3], hi[3];
+    uint32_t first, n;
+    uint32_t left;          // BFS index of the left child (right = left + 1), kNone = leaf
+    uint32_t size;          // |desc(X)| in nodes
+    uint32_t dfs;           // index in the reference's node array
+    uint32_t base;          // where desc(X) starts in the reference's node array
+};
+
+// order-preserving float <-> uint key (so LDS integer min/max atomics give float min/max)
+__device__ __forceinline__ uint32_t fkey(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float funkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ float box_area(const float *lo, const float *hi) {        // Node::surface_area, bvh.rs:196-203
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return (ex * ez) + (ex * ey) + (ez * ey);
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total = block sum
+__device__ uint32_t block_exscan(uint32_t v, uint32_t *s_warp, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+    if (lane == 63u) s_warp[w] = x;
+    __syncthreads();
+    uint32_t add = 0, tot = 0;
+    for (uint32_t i = 0; i < 4u; i++) { const uint32_t sw = s_warp[i]; if (i < w) add += sw; tot += sw; }
+    __syncthreads();
+    *total = tot;
+    return add + x - v;
+}
+
+__global__ void make_proxies(const MiptTriangle *tris, uint32_t n, Proxy *px, uint32_t *rootkeys) {
+    __shared__ uint32_t s_lo[3], s_hi[3];
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0xffffffffu; s_hi[threadIdx.x] = 0u; }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Proxy p;
+        p.idx = i;
+        for (int a = 0; a < 3; a++) {
+            float mn = F32_MAX, mx = -F32_MAX;                                          // scene.rs:115-123, bvh.rs:185-194
+            for (int v = 0; v < 3; v++) { const float q = (&tris[i].vertices[v].position.x)[a]; mn = fminf(mn, q); mx = fmaxf(mx, q); }
+            p.lo[a] = mn; p.hi[a] = mx; p.c[a] = (mn + mx) / 2.0f;                      // scene.rs:125
+            atomicMin(&s_lo[a], fkey(mn)); atomicMax(&s_hi[a], fkey(mx));
+        }
+        px[i] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&rootkeys[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&rootkeys[3 + threadIdx.x], s_hi[threadIdx.x]); }
+}
+
+__global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
+    BNode r;
+    for (int a = 0; a < 3; a++) { r.lo[a] = funkey(rootkeys[a]); r.hi[a] = funkey(rootkeys[3 + a]); }
+    r.first = 0; r.n = n; r.left = kNone; r.size = 0; r.dfs = 0; r.base = 1;
+    bn[0] = r;
+}
+
+// one workgroup per node of the level [lvl_begin, lvl_begin + gridDim.x)
+__global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+                                                  uint32_t *hole_pos, uint32_t *tail_pos, uint32_t *n_nodes) {
+    __shared__ uint32_t s_key[3][8][6];      // per axis, per bin: lo.xyz (min keys), hi.xyz (max keys)
+    __shared__ uint32_t s_cnt[3][8];
+    __shared__ uint32_t s_cmin[3], s_cmax[3];
+    __shared__ uint32_t s_ckey[2][6];        // child boxes (L, R)
+    __shared__ uint32_t s_warp[4];
+    __shared__ float s_pos[3][8];
+    __shared__ int s_use[3];
+    __shared__ int s_split, s_axis;
+    __shared__ float s_splitpos;
+    __shared__ uint32_t s_k;
+
+    const uint32_t node_i = lvl_begin + blockIdx.x;
+    const BNode nd = bn[node_i];
+    const uint32_t first = nd.first, n = nd.n, tid = threadIdx.x;
+    const Proxy *in = pin + first;
+    Proxy *out = pout + first;
+
+    // ---- 1. centroid ranges (bvh.rs:67-77; f32::MIN == -f32::MAX) ----
+    if (tid < 3) { s_cmin[tid] = 0xffffffffu; s_cmax[tid] = 0u; }
+    for (uint32_t i = tid; i < 3 * 8 * 6; i += kT) (&s_key[0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+    for (uint32_t i = tid; i < 3 * 8; i += kT) (&s_cnt[0][0])[i] = 0u;
+    if (tid < 12) (&s_ckey[0][0])[tid] = ((tid % 6) < 3) ? 0xffffffffu : 0u;
+    __syncthreads();
+    {
+        float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+        for (uint32_t i = tid; i < n; i += kT)
+            for (int a = 0; a < 3; a++) { const float c = in[i].c[a]; mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c); }
+        for (int a = 0; a < 3; a++) { atomicMin(&s_cmin[a], fkey(mn[a])); atomicMax(&s_cmax[a], fkey(mx[a])); }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const float cmin = funkey(s_cmin[tid]), cmax = funkey(s_cmax[tid]);
+        s_use[tid] = !(cmin == cmax);                                                   // bvh.rs:78
+        const float scale = (cmax - cmin) / 8.0f;                                       // bvh.rs:82
+        for (int i = 1; i < 8; i++) s_pos[tid][i] = cmin + (float)i * scale;            // bvh.rs:84
+    }
+    __syncthreads();
+    // ---- 2. binning: bin = first plane i (1..7) with c < pos_i, else 8 (stored at i-1) ----
+    for (uint32_t i = tid; i < n; i += kT) {
+        const Proxy p = in[i];
+        for (int a = 0; a < 3; a++) {
+            if (!s_use[a]) continue;
+            int k = 8;
+            for (int j = 1; j < 8; j++) if (p.c[a] < s_pos[a][j]) { k = j; break; }
+            uint32_t *key = s_key[a][k - 1];
+            for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
+            atomicAdd(&s_cnt[a][k - 1], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- 3. SAH (bvh.rs:58-97, 138-161) ----
+    if (tid == 0) {
+        const float parent_cost = (float)n * box_area(nd.lo, nd.hi);
+        float best_cost = F32_MAX, best_pos = 0.0f;
+        int best_axis = 0;
+        for (int a = 0; a < 3; a++) {
+            if (!s_use[a]) continue;
+            float rlo[8][3], rhi[8][3];
+            uint32_t rcnt[8];
+            float alo[3] = {F32_MAX, F32_MAX, F32_MAX}, ahi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            uint32_t c = 0;
+            for (int k = 7; k >= 0; k--) {
+                for (int q = 0; q < 3; q++) { alo[q] = fminf(alo[q], funkey(s_key[a][k][q])); ahi[q] = fmaxf(ahi[q], funkey(s_key[a][k][3 + q])); }
+                // (an empty bin's untouched keys decode to NaN, which fminf/fmaxf ignore: same as merging Node::default())
+                c += s_cnt[a][k];
+                for (int q = 0; q < 3; q++) { rlo[k][q] = alo[q]; rhi[k][q] = ahi[q]; }
+                rcnt[k] = c;
+            }
+            float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            uint32_t lc = 0;
+            for (int i = 1; i < 8; i++) {
+                for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(s_key[a][i - 1][q])); lhi[q] = fmaxf(lhi[q], funkey(s_key[a][i - 1][3 + q])); }
+                lc += s_cnt[a][i - 1];
+                const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
+                const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
+                if (split_cost < best_cost) { best_axis = a; best_pos = s_pos[a][i]; best_cost = split_cost; }
+            }
+        }
+        s_split = !(best_cost >= parent_cost);                                          // bvh.rs:94
+        s_axis = best_axis; s_splitpos = best_pos;
+    }
+    __syncthreads();
+    if (!s_split) {                                   // leaf: carry the range over unchanged
+        for (uint32_t i = tid; i < n; i += kT) out[i] = in[i];
+        return;
+    }
+    const int axis = s_axis;
+    const float pos = s_splitpos;
+    // ---- 4. the partition permutation ----
+    uint32_t cnt = 0;
+    for (uint32_t i = tid; i < n; i += kT) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
+    {
+        uint32_t tot;
+        (void)block_exscan(cnt, s_warp, &tot);
+        if (tid == 0) s_k = tot;
+    }
+    __syncthreads();
+    const uint32_t k = s_k;
+    uint32_t *hp = hole_pos + first, *tp = tail_pos + first;
+    // holes: positions p < k holding ">=", in increasing p  ->  hp[m] = p
+    uint32_t n_holes = 0;
+    for (uint32_t base = 0; base < k; base += kT) {
+        const uint32_t p = base + tid;
+        const uint32_t f = (p < k && !(in[p].c[axis] < pos)) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (f) hp[n_holes + r] = p;
+        n_holes += tot;
+    }
+    // tail "<": positions p >= k holding "<", in decreasing p  ->  tp[m] = p
+    uint32_t n_tail = 0;
+    for (uint32_t base = 0; base < n - k; base += kT) {
+        const uint32_t q = base + tid;                  // q-th position from the end
+        const uint32_t p = n - 1u - q;
+        const uint32_t f = (q < n - k && (in[p].c[axis] < pos)) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (f) tp[n_tail + r] = p;
+        n_tail += tot;
+    }
+    __threadfence();                                    // hp / tp are read by other threads of this block below
+    __syncthreads();
+    const uint32_t t_last = n_holes ? __hip_atomic_load(&tp[n_holes - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
+    // scatter + child boxes
+    uint32_t hole_rank_base = 0, tail_seen = 0;
+    (void)tail_seen;
+    float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
+    // (a) positions < k: forward, hole rank by scan
+    for (uint32_t base = 0; base < k; base += kT) {
+        const uint32_t p = base + tid;
+        Proxy e;
+        uint32_t f = 0;
+        if (p < k) { e = in[p]; f = !(e.c[axis] < pos) ? 1u : 0u; }
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (p < k) {
+            uint32_t dest;
+            if (!f) dest = p;
+            else {
+                const uint32_t m = hole_rank_base + r;
+                const uint32_t tprev = m ? __hip_atomic_load(&tp[m - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
+                dest = tprev - 1u;
+            }
+            out[dest] = e;
+            const int side = f ? 1 : 0;
+            for (int q = 0; q < 3; q++) { clo[side][q] = fminf(clo[side][q], e.lo[q]); chi[side][q] = fmaxf(chi[side][q], e.hi[q]); }
+        }
+        hole_rank_base += tot;
+    }
+    // (b) positions >= k: from the end, tail rank by scan
+    uint32_t tail_rank_base = 0;
+    for (uint32_t base = 0; base < n - k; base += kT) {
+        const uint32_t q = base + tid;
+        const uint32_t p = n - 1u - q;
+        Proxy e;
+        uint32_t f = 0;
+        const bool valid = q < n - k;
+        if (valid) { e = in[p]; f = (e.c[axis] < pos) ? 1u : 0u; }
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (valid) {
+            uint32_t dest;
+            if (f) dest = __hip_atomic_load(&hp[tail_rank_base + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (p > t_last) dest = p - 1u;
+            else dest = (p == k) ? (t_last - 1u) : (p - 1u);
+            out[dest] = e;
+            const int side = f ? 0 : 1;
+            for (int qq = 0; qq < 3; qq++) { clo[side][qq] = fminf(clo[side][qq], e.lo[qq]); chi[side][qq] = fmaxf(chi[side][qq], e.hi[qq]); }
+        }
+        tail_rank_base += tot;
+    }
+    for (int sd = 0; sd < 2; sd++)
+        for (int q = 0; q < 3; q++) { atomicMin(&s_ckey[sd][q], fkey(clo[sd][q])); atomicMax(&s_ckey[sd][3 + q], fkey(chi[sd][q])); }
+    __syncthreads();
+    // ---- 5. children (bvh.rs:115-132) ----
+    if (tid == 0) {
+        const uint32_t base = atomicAdd(n_nodes, 2u);
+        BNode a, b;
+        for (int q = 0; q < 3; q++) { a.lo[q] = funkey(s_ckey[0][q]); a.hi[q] = funkey(s_ckey[0][3 + q]); b.lo[q] = funkey(s_ckey[1][q]); b.hi[q] = funkey(s_ckey[1][3 + q]); }
+        a.first = first; a.n = k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
+        b.first = first + k; b.n = n - k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
+        bn[base] = a; bn[base + 1] = b;
+        bn[node_i].left = base;
+    }
+}
+
+__global__ void sizes_level(BNode *bn, uint32_t begin, uint32_t end) {              // bottom-up: |desc(X)|
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const uint32_t l = bn[i].left;
+        bn[i].size = (l == kNone) ? 0u : 2u + bn[l].size + bn[l + 1].size;
+    }
+}
+__global__ void bases_level(BNode *bn, uint32_t begin, uint32_t end) {              // top-down: desc(X) = [A, B] ++ desc(A) ++ desc(B)
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const uint32_t l = bn[i].left;
+        if (l == kNone) continue;
+        const uint32_t b = bn[i].base;
+        bn[l].dfs = b; bn[l + 1].dfs = b + 1u;
+        bn[l].base = b + 2u; bn[l + 1].base = b + 2u + bn[l].size;
+    }
+}
+__global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, MiptNode *nodes) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x) {
+        const BNode b = bn[i];
+        MiptNode nd;
+        nd.bounds_min = {b.lo[0], b.lo[1], b.lo[2]}; nd.bounds_max = {b.hi[0], b.hi[1], b.hi[2]};
+        if (b.left == kNone) { nd.first_tri_or_child = b.first; nd.num_tris = b.n; }
+        else { nd.first_tri_or_child = b.base; nd.num_tris = 0; }
+        nodes[b.dfs] = nd;
+    }
+}
+__global__ void gather_tris(const MiptTriangle *src, const Proxy *px, uint32_t n, MiptTriangle *dst) {
+    // 112-B records as 7 x 16 B; one thread per (triangle, 16-B piece)
+    const unsigned long long total = (unsigned long long)n * 7ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t t = (uint32_t)(i / 7ull), piece = (uint32_t)(i % 7ull);
+        reinterpret_cast<float4 *>(dst)[(unsigned long long)t * 7ull + piece] = reinterpret_cast<const float4 *>(src)[(unsigned long long)px[t].idx * 7ull + piece];
+    }
+}
+
+int fail(int code, const char *what, hipError_t e) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "mipt_bvh_build_device: %s: %s", what, hipGetErrorString(e));
+    mipt_internal_set_error(buf);
+    return code;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MIPT_ERR_HIP, #x, e_); } } while (0)
+
+} // namespace
+
+extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
+                                     uint32_t *n_nodes_out, int device_id, double *build_ms_out) {
+    if (!tris || !nodes_out || n_tris == 0 || nodes_cap == 0) { mipt_internal_set_error("mipt_bvh_build_device: bad argument (empty scene: the reference panics)"); return MIPT_ERR_INVALID_ARG; }
+    MiptTriangle *d_tris = nullptr, *d_out = nullptr;
+    Proxy *d_px[2] = {nullptr, nullptr};
+    BNode *d_bn = nullptr;
+    MiptNode *d_nodes = nullptr;
+    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_cnt = nullptr, *d_root = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_cnt, d_root};
+        for (void *q : p) if (q) (void)hipFree(q);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    HIP_TRY(hipSetDevice(device_id));
+    const size_t nb = (size_t)n_tris * sizeof(MiptTriangle);
+    const uint32_t max_nodes = 2u * n_tris;
+    HIP_TRY(hipMalloc((void **)&d_tris, nb));
+    HIP_TRY(hipMalloc((void **)&d_out, nb));
+    HIP_TRY(hipMalloc((void **)&d_px[0], (size_t)n_tris * sizeof(Proxy)));
+    HIP_TRY(hipMalloc((void **)&d_px[1], (size_t)n_tris * sizeof(Proxy)));
+    HIP_TRY(hipMalloc((void **)&d_bn, (size_t)max_nodes * sizeof(BNode)));
+    HIP_TRY(hipMalloc((void **)&d_nodes, (size_t)max_nodes * sizeof(MiptNode)));
+    HIP_TRY(hipMalloc((void **)&d_hp, (size_t)n_tris * 4));
+    HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
+    HIP_TRY(hipMalloc((void **)&d_cnt, 4));
+    HIP_TRY(hipMalloc((void **)&d_root, 24));
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
+    const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    const uint32_t one = 1u;
+    HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_cnt, &one, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(make_proxies, dim3(2048), dim3(256), 0, nullptr, d_tris, n_tris, d_px[0], d_root);
+    hipLaunchKernelGGL(init_root, dim3(1), dim3(1), 0, nullptr, d_bn, d_root, n_tris);
+    std::vector<uint32_t> lvl_begin;
+    uint32_t begin = 0, end = 1;
+    int cur = 0;
+    while (begin < end) {                               // one launch per tree level; every level strictly grows `end` or stops
+        lvl_begin.push_back(begin);
+        hipLaunchKernelGGL(build_level, dim3(end - begin), dim3(kT), 0, nullptr, d_bn, begin, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_cnt);
+        HIP_TRY(hipGetLastError());
+        uint32_t total = 0;
+        HIP_TRY(hipMemcpy(&total, d_cnt, 4, hipMemcpyDeviceToHost));
+        if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
+        begin = end; end = total; cur ^= 1;
+        if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
+    }
+    const uint32_t n_nodes = end;
+    lvl_begin.push_back(n_nodes);
+    if (n_nodes > nodes_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: nodes_cap too small"); return MIPT_ERR_INVALID_ARG; }
+    for (int l = (int)lvl_begin.size() - 2; l >= 0; l--) {
+        const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
+        hipLaunchKernelGGL(sizes_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+    }
+    for (size_t l = 0; l + 1 < lvl_begin.size(); l++) {
+        const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
+        hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+    }
+    hipLaunchKernelGGL(emit_nodes, dim3(2048), dim3(256), 0, nullptr, d_bn, n_nodes, d_nodes);
+    hipLaunchKernelGGL(gather_tris, dim3(4096), dim3(256), 0, nullptr, d_tris, d_px[cur], n_tris, d_out);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipMemcpy(tris, d_out, nb, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nodes_out, d_nodes, (size_t)n_nodes * sizeof(MiptNode), hipMemcpyDeviceToHost));
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+    if (build_ms_out) *build_ms_out = ms;
+    cleanup();
+    return MIPT_OK;
+}

@@ -138,6 +138,18 @@ class Scene:  # scene.rs:12-19
         self.bvh_nodes = nodes[: count.value].copy()
         self.release()
 
+    def build_bvh_device(self, device_id: int = 0) -> float:
+        """BVH::build on the GPU (mipt_bvh_build_device); returns the device build time in ms."""
+        n = len(self.tris)
+        nodes = np.zeros(max(2 * n, 1), dtype=L.NODE)
+        count = C.c_uint32(0)
+        ms = C.c_double(0.0)
+        L.check(L.load().mipt_bvh_build_device(L.ptr(self.tris), n, L.ptr(nodes), len(nodes), C.byref(count), device_id, C.byref(ms)),
+                "mipt_bvh_build_device")
+        self.bvh_nodes = nodes[: count.value].copy()
+        self.release()
+        return ms.value
+
     def set_camera(self, camera: Camera) -> None:  # scene.rs:38-41
         self.camera = camera
         self.camera.update_view()

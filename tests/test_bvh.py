@@ -86,3 +86,41 @@ def test_random_soups_match_oracle(rrt, orc, spec):
     sc, ot, on = build_both(rrt, orc, t)
     assert sc.tris.tobytes() == ot.tobytes()
     assert canon(sc.bvh_nodes, NODE) == canon(on, NODE)
+
+
+def test_partition_closed_form():
+    """The reference's partition loop (bvh.rs:99-108) is sequential; the GPU builder uses its closed-form permutation
+    (bvh_build_device.hip header).  Brute force: the closed form reproduces the loop on 10^5 random flag vectors."""
+    def seq(is_l):
+        a = list(range(len(is_l)))
+        i, j = 0, len(a) - 1
+        while i <= j:
+            if is_l[a[i]]:
+                i += 1
+            else:
+                a[i], a[j] = a[j], a[i]
+                j -= 1
+        return a
+
+    def closed(is_l):
+        n = len(is_l)
+        is_l = np.asarray(is_l, bool)
+        k = int(is_l.sum())
+        pos = np.arange(n)
+        out = np.full(n, -1)
+        stay = (pos < k) & is_l
+        out[pos[stay]] = pos[stay]
+        holes = pos[(pos < k) & ~is_l]
+        tail_l = pos[(pos >= k) & is_l][::-1]
+        out[holes] = tail_l
+        for m, hh in enumerate(holes):
+            out[(n if m == 0 else tail_l[m - 1]) - 1] = hh
+        t_last = tail_l[-1] if len(tail_l) else n
+        for p in pos[(pos >= k) & ~is_l]:
+            out[(t_last - 1) if (p <= t_last and p == k) else p - 1] = p
+        return list(out)
+    rng = np.random.default_rng(0)
+    for _ in range(100000):
+        n = int(rng.integers(1, 30))
+        flags = (rng.random(n) < rng.random()).tolist()
+        assert seq(flags) == closed(flags)

@@ -1,0 +1,27 @@
+"""GPU box: device BVH builder vs host builder (bit-identical up to the sign of zero), with timings."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rust_ray_tracing_amd as rrt
+from rust_ray_tracing_amd import synth, NODE, TRIANGLE
+def canon(n):
+    n = n.copy()
+    for k in ("bounds_min", "bounds_max"): n[k] = n[k] + np.float32(0.0)
+    return n.tobytes()
+cases = [("cornell", {}), ("helmet", dict(n_target=4000, tex_size=16)), ("dragon", dict(n_target=30000)), ("atrium", dict(n_target=60000, tex_size=16)),
+         ("atrium", dict(n_target=1_000_000, tex_size=16))]
+if len(sys.argv) > 1: cases.append(("atrium", dict(n_target=10_000_000, tex_size=16)))
+for kind, kw in cases:
+    tris = synth.make_scene(kind, **kw)[0]
+    a = rrt.Scene.from_arrays(tris, [rrt.material_default()], build_bvh=False)
+    b = rrt.Scene.from_arrays(tris, [rrt.material_default()], build_bvh=False)
+    t0 = time.time(); a.build_bvh(); t1 = time.time()
+    ms = b.build_bvh_device(0); t2 = time.time()
+    same_n = canon(a.bvh_nodes) == canon(b.bvh_nodes)
+    same_t = a.tris.tobytes() == b.tris.tobytes()
+    print(f"{kind} {len(tris)} tris: nodes {len(a.bvh_nodes)}/{len(b.bvh_nodes)} equal {same_n}, tris equal {same_t}; host {1e3*(t1-t0):.0f} ms, device build {ms:.1f} ms (call {1e3*(t2-t1):.0f} ms)", flush=True)
+    if not (same_n and same_t):
+        n = min(len(a.bvh_nodes), len(b.bvh_nodes))
+        bad = [i for i in range(n) if canon(a.bvh_nodes[i:i+1]) != canon(b.bvh_nodes[i:i+1])][:5]
+        print("  first differing nodes", bad, [(a.bvh_nodes[i], b.bvh_nodes[i]) for i in bad[:2]])
+        break
