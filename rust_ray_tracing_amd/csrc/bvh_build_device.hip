@@ -31,6 +31,9 @@ namespace {
 constexpr int kT = 256;
 constexpr float F32_MAX = FLT_MAX;
 constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kBig = 32768;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
+constexpr uint32_t kChunk = 8192;
+constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
 
 struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
 struct BNode {
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
     const uint32_t node_i = lvl_begin + blockIdx.x;
     const BNode nd = bn[node_i];
     const uint32_t first = nd.first, n = nd.n, tid = threadIdx.x;
+    if (n > kBig || n <= kTiny) return;         // handled by the multi-workgroup kernels / the one-thread-per-node kernel
     const Proxy *in = pin + first;
     Proxy *out = pout + first;
 
@@ -281,6 +285,325 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
     }
 }
 
+// ---- nodes with <= kTiny triangles: one thread per node, the reference's own loops (bvh.rs:56-161) on the proxies ----------
+__device__ __forceinline__ void grow(float *lo, float *hi, const Proxy &p) {
+    for (int q = 0; q < 3; q++) { lo[q] = fminf(lo[q], p.lo[q]); hi[q] = fmaxf(hi[q], p.hi[q]); }
+}
+__global__ void build_level_tiny(BNode *bn, uint32_t lvl_begin, uint32_t lvl_end, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+                                 uint32_t *n_nodes) {
+    const uint32_t node_i = lvl_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (node_i >= lvl_end) return;
+    const BNode nd = bn[node_i];
+    const uint32_t n = nd.n;
+    if (n > kTiny) return;
+    const Proxy *in = pin + nd.first;
+    Proxy *out = pout + nd.first;
+    for (uint32_t i = 0; i < n; i++) out[i] = in[i];
+    const float parent_cost = (float)n * box_area(nd.lo, nd.hi);
+    int best_axis = 0;
+    float best_pos = 0.0f, best_cost = F32_MAX;
+    for (int a = 0; a < 3; a++) {
+        float cmin = F32_MAX, cmax = -F32_MAX;
+        for (uint32_t i = 0; i < n; i++) { const float c = in[i].c[a]; cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); }
+        if (cmin == cmax) continue;
+        const float scale = (cmax - cmin) / 8.0f;
+        for (int i = 1; i < 8; i++) {
+            const float pos = cmin + (float)i * scale;
+            float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            float rlo[3] = {F32_MAX, F32_MAX, F32_MAX}, rhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            uint32_t lc = 0, rc = 0;
+            for (uint32_t t = 0; t < n; t++) {                                            // evaluate_sah, bvh.rs:138-161
+                const Proxy p = in[t];
+                if (p.c[a] < pos) { grow(llo, lhi, p); lc++; } else { grow(rlo, rhi, p); rc++; }
+            }
+            const float cost = (float)lc * box_area(llo, lhi) + (float)rc * box_area(rlo, rhi);
+            const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
+            if (split_cost < best_cost) { best_axis = a; best_pos = pos; best_cost = split_cost; }
+        }
+    }
+    if (best_cost >= parent_cost) return;                                                 // leaf (bvh.rs:94); range already copied
+    uint32_t i = 0, j = n - 1u;                                                           // bvh.rs:99-108 on `out`
+    while (i <= j) {
+        if (out[i].c[best_axis] < best_pos) i++;
+        else {
+            const Proxy t = out[i]; out[i] = out[j]; out[j] = t;
+            if (j == 0u) break;
+            j--;
+        }
+    }
+    const uint32_t k = i;
+    if (k == 0u || k == n) return;
+    BNode a, b;
+    for (int q = 0; q < 3; q++) { a.lo[q] = F32_MAX; a.hi[q] = -F32_MAX; b.lo[q] = F32_MAX; b.hi[q] = -F32_MAX; }
+    for (uint32_t t = 0; t < k; t++) grow(a.lo, a.hi, out[t]);
+    for (uint32_t t = k; t < n; t++) grow(b.lo, b.hi, out[t]);
+    const uint32_t base = atomicAdd(n_nodes, 2u);
+    a.first = nd.first; a.n = k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
+    b.first = nd.first + k; b.n = n - k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
+    bn[base] = a; bn[base + 1] = b;
+    bn[node_i].left = base;
+}
+
+// ---- nodes with > kBig triangles: the same five steps, spread over one workgroup per kChunk elements ---------------------
+struct BigState {
+    uint32_t node;                 // BFS index
+    uint32_t first, n;
+    uint32_t cmin[3], cmax[3];     // keys
+    float pos[3][8];
+    int use[3];
+    uint32_t key[3][8][6];
+    uint32_t cnt[3][8];
+    int split, axis;
+    float splitpos;
+    uint32_t k, n_holes;
+    uint32_t ckey[2][6];
+    float lo[3], hi[3];            // node bounds
+};
+struct ChunkInfo { uint32_t big, off, len, hole_cnt, tail_cnt, hole_base, tail_base, pad; };
+
+__global__ void big_init(BigState *bs, const BNode *bn, const uint32_t *ids, uint32_t nb) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    BigState s;
+    memset(&s, 0, sizeof s);
+    const BNode nd = bn[ids[j]];
+    s.node = ids[j]; s.first = nd.first; s.n = nd.n;
+    for (int a = 0; a < 3; a++) { s.cmin[a] = 0xffffffffu; s.cmax[a] = 0u; s.lo[a] = nd.lo[a]; s.hi[a] = nd.hi[a]; }
+    for (int a = 0; a < 3; a++) for (int k = 0; k < 8; k++) for (int q = 0; q < 6; q++) s.key[a][k][q] = q < 3 ? 0xffffffffu : 0u;
+    for (int sd = 0; sd < 2; sd++) for (int q = 0; q < 6; q++) s.ckey[sd][q] = q < 3 ? 0xffffffffu : 0u;
+    bs[j] = s;
+}
+__global__ __launch_bounds__(kT) void big_range(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
+    __shared__ uint32_t s_mn[3], s_mx[3];
+    const ChunkInfo c = ch[blockIdx.x];
+    BigState *b = bs + c.big;
+    const Proxy *in = pin + b->first + c.off;
+    if (threadIdx.x < 3) { s_mn[threadIdx.x] = 0xffffffffu; s_mx[threadIdx.x] = 0u; }
+    __syncthreads();
+    float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+    for (uint32_t i = threadIdx.x; i < c.len; i += kT)
+        for (int a = 0; a < 3; a++) { const float v = in[i].c[a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    for (int a = 0; a < 3; a++) { atomicMin(&s_mn[a], fkey(mn[a])); atomicMax(&s_mx[a], fkey(mx[a])); }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&b->cmin[threadIdx.x], s_mn[threadIdx.x]); atomicMax(&b->cmax[threadIdx.x], s_mx[threadIdx.x]); }
+}
+__global__ void big_planes(BigState *bs, uint32_t nb) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb * 3u) return;
+    BigState *b = bs + j / 3u;
+    const int a = (int)(j % 3u);
+    const float cmin = funkey(b->cmin[a]), cmax = funkey(b->cmax[a]);
+    b->use[a] = !(cmin == cmax);
+    const float scale = (cmax - cmin) / 8.0f;
+    for (int i = 1; i < 8; i++) b->pos[a][i] = cmin + (float)i * scale;
+}
+__global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
+    __shared__ uint32_t s_key[3][8][6];
+    __shared__ uint32_t s_cnt[3][8];
+    __shared__ float s_pos[3][8];
+    __shared__ int s_use[3];
+    const ChunkInfo c = ch[blockIdx.x];
+    BigState *b = bs + c.big;
+    const Proxy *in = pin + b->first + c.off;
+    for (uint32_t i = threadIdx.x; i < 144; i += kT) (&s_key[0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+    if (threadIdx.x < 24) { (&s_cnt[0][0])[threadIdx.x] = 0u; (&s_pos[0][0])[threadIdx.x] = (&b->pos[0][0])[threadIdx.x]; }
+    if (threadIdx.x < 3) s_use[threadIdx.x] = b->use[threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < c.len; i += kT) {
+        const Proxy p = in[i];
+        for (int a = 0; a < 3; a++) {
+            if (!s_use[a]) continue;
+            int k = 8;
+            for (int j = 1; j < 8; j++) if (p.c[a] < s_pos[a][j]) { k = j; break; }
+            uint32_t *key = s_key[a][k - 1];
+            for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
+            atomicAdd(&s_cnt[a][k - 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 144; i += kT) {
+        const uint32_t v = (&s_key[0][0][0])[i];
+        if ((i % 6) < 3) atomicMin(&(&b->key[0][0][0])[i], v); else atomicMax(&(&b->key[0][0][0])[i], v);
+    }
+    if (threadIdx.x < 24 && (&s_cnt[0][0])[threadIdx.x]) atomicAdd(&(&b->cnt[0][0])[threadIdx.x], (&s_cnt[0][0])[threadIdx.x]);
+}
+__global__ void big_choose(BigState *bs, uint32_t nb) {                              // same expression order as build_level step 3
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    BigState *b = bs + j;
+    const float parent_cost = (float)b->n * box_area(b->lo, b->hi);
+    float best_cost = F32_MAX, best_pos = 0.0f;
+    int best_axis = 0;
+    for (int a = 0; a < 3; a++) {
+        if (!b->use[a]) continue;
+        float rlo[8][3], rhi[8][3];
+        uint32_t rcnt[8];
+        float alo[3] = {F32_MAX, F32_MAX, F32_MAX}, ahi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+        uint32_t c = 0;
+        for (int k = 7; k >= 0; k--) {
+            for (int q = 0; q < 3; q++) { alo[q] = fminf(alo[q], funkey(b->key[a][k][q])); ahi[q] = fmaxf(ahi[q], funkey(b->key[a][k][3 + q])); }
+            c += b->cnt[a][k];
+            for (int q = 0; q < 3; q++) { rlo[k][q] = alo[q]; rhi[k][q] = ahi[q]; }
+            rcnt[k] = c;
+        }
+        float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+        uint32_t lc = 0;
+        for (int i = 1; i < 8; i++) {
+            for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(b->key[a][i - 1][q])); lhi[q] = fmaxf(lhi[q], funkey(b->key[a][i - 1][3 + q])); }
+            lc += b->cnt[a][i - 1];
+            const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
+            const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
+            if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; }
+        }
+    }
+    b->split = !(best_cost >= parent_cost);
+    b->axis = best_axis; b->splitpos = best_pos;
+}
+__global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
+    __shared__ uint32_t s_warp[4];
+    const ChunkInfo c = ch[blockIdx.x];
+    BigState *b = bs + c.big;
+    if (!b->split) return;
+    const Proxy *in = pin + b->first + c.off;
+    const int axis = b->axis; const float pos = b->splitpos;
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < c.len; i += kT) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
+    uint32_t tot;
+    (void)block_exscan(cnt, s_warp, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(&b->k, tot);
+}
+__global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, const Proxy *__restrict__ pin) {   // holes / tail-"<" per chunk
+    __shared__ uint32_t s_warp[4];
+    ChunkInfo c = ch[blockIdx.x];
+    BigState *b = bs + c.big;
+    if (!b->split) return;
+    const Proxy *in = pin + b->first + c.off;
+    const int axis = b->axis; const float pos = b->splitpos; const uint32_t k = b->k;
+    uint32_t holes = 0, tails = 0;
+    for (uint32_t i = threadIdx.x; i < c.len; i += kT) {
+        const uint32_t p = c.off + i;
+        const bool l = in[i].c[axis] < pos;
+        holes += (p < k && !l) ? 1u : 0u;
+        tails += (p >= k && l) ? 1u : 0u;
+    }
+    uint32_t th, tt;
+    (void)block_exscan(holes, s_warp, &th);
+    (void)block_exscan(tails, s_warp, &tt);
+    if (threadIdx.x == 0) { ch[blockIdx.x].hole_cnt = th; ch[blockIdx.x].tail_cnt = tt; }
+}
+// one thread per big node: chunk bases (chunks of a node are contiguous in the chunk table, increasing offset)
+__global__ void big_scan(BigState *bs, ChunkInfo *ch, const uint32_t *chunk_begin, uint32_t nb) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb || !bs[j].split) return;
+    const uint32_t cb = chunk_begin[j], ce = chunk_begin[j + 1];
+    uint32_t acc = 0;
+    for (uint32_t c = cb; c < ce; c++) { ch[c].hole_base = acc; acc += ch[c].hole_cnt; }
+    bs[j].n_holes = acc;
+    acc = 0;
+    for (uint32_t c = ce; c-- > cb;) { ch[c].tail_base = acc; acc += ch[c].tail_cnt; }
+}
+__global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, uint32_t *hole_pos, uint32_t *tail_pos) {
+    __shared__ uint32_t s_warp[4];
+    const ChunkInfo c = ch[blockIdx.x];
+    const BigState *b = bs + c.big;
+    if (!b->split) return;
+    const Proxy *in = pin + b->first + c.off;
+    uint32_t *hp = hole_pos + b->first, *tp = tail_pos + b->first;
+    const int axis = b->axis; const float pos = b->splitpos; const uint32_t k = b->k;
+    uint32_t hb = c.hole_base, tb = c.tail_base;
+    for (uint32_t base = 0; base < c.len; base += kT) {                 // holes: increasing p
+        const uint32_t i = base + threadIdx.x, p = c.off + i;
+        const uint32_t f = (i < c.len && p < k && !(in[i].c[axis] < pos)) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (f) hp[hb + r] = p;
+        hb += tot;
+    }
+    for (uint32_t base = 0; base < c.len; base += kT) {                 // tail "<": decreasing p
+        const uint32_t q = base + threadIdx.x;
+        const uint32_t i = c.len - 1u - q, p = c.off + i;
+        const uint32_t f = (q < c.len && p >= k && (in[i].c[axis] < pos)) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (f) tp[tb + r] = p;
+        tb += tot;
+    }
+}
+__global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+                                                  const uint32_t *hole_pos, const uint32_t *tail_pos) {
+    __shared__ uint32_t s_warp[4];
+    __shared__ uint32_t s_ckey[2][6];
+    const ChunkInfo c = ch[blockIdx.x];
+    BigState *b = bs + c.big;
+    const Proxy *in = pin + b->first + c.off;
+    Proxy *out = pout + b->first;
+    if (!b->split) { for (uint32_t i = threadIdx.x; i < c.len; i += kT) out[c.off + i] = in[i]; return; }
+    const uint32_t *hp = hole_pos + b->first, *tp = tail_pos + b->first;
+    const int axis = b->axis; const float pos = b->splitpos; const uint32_t k = b->k, n = b->n, n_holes = b->n_holes;
+    if (threadIdx.x < 12) (&s_ckey[0][0])[threadIdx.x] = ((threadIdx.x % 6) < 3) ? 0xffffffffu : 0u;
+    __syncthreads();
+    const uint32_t t_last = n_holes ? tp[n_holes - 1u] : n;
+    float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
+    uint32_t hb = c.hole_base;
+    for (uint32_t base = 0; base < c.len; base += kT) {                 // positions < k, increasing
+        const uint32_t i = base + threadIdx.x, p = c.off + i;
+        const bool valid = i < c.len && p < k;
+        Proxy e;
+        uint32_t f = 0;
+        if (valid) { e = in[i]; f = !(e.c[axis] < pos) ? 1u : 0u; }
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (valid) {
+            uint32_t dest = p;
+            if (f) { const uint32_t m = hb + r; dest = (m ? tp[m - 1u] : n) - 1u; }
+            out[dest] = e;
+            const int side = f ? 1 : 0;
+            for (int q = 0; q < 3; q++) { clo[side][q] = fminf(clo[side][q], e.lo[q]); chi[side][q] = fmaxf(chi[side][q], e.hi[q]); }
+        }
+        hb += tot;
+    }
+    uint32_t tb = c.tail_base;
+    for (uint32_t base = 0; base < c.len; base += kT) {                 // positions >= k, decreasing
+        const uint32_t q = base + threadIdx.x;
+        const uint32_t i = c.len - 1u - q, p = c.off + i;
+        const bool valid = q < c.len && p >= k;
+        Proxy e;
+        uint32_t f = 0;
+        if (valid) { e = in[i]; f = (e.c[axis] < pos) ? 1u : 0u; }
+        uint32_t tot;
+        const uint32_t r = block_exscan(f, s_warp, &tot);
+        if (valid) {
+            uint32_t dest;
+            if (f) dest = hp[tb + r];
+            else if (p > t_last) dest = p - 1u;
+            else dest = (p == k) ? (t_last - 1u) : (p - 1u);
+            out[dest] = e;
+            const int side = f ? 0 : 1;
+            for (int qq = 0; qq < 3; qq++) { clo[side][qq] = fminf(clo[side][qq], e.lo[qq]); chi[side][qq] = fmaxf(chi[side][qq], e.hi[qq]); }
+        }
+        tb += tot;
+    }
+    for (int sd = 0; sd < 2; sd++)
+        for (int q = 0; q < 3; q++) { atomicMin(&s_ckey[sd][q], fkey(clo[sd][q])); atomicMax(&s_ckey[sd][3 + q], fkey(chi[sd][q])); }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const uint32_t v = (&s_ckey[0][0])[threadIdx.x];
+        if ((threadIdx.x % 6) < 3) atomicMin(&(&b->ckey[0][0])[threadIdx.x], v); else atomicMax(&(&b->ckey[0][0])[threadIdx.x], v);
+    }
+}
+__global__ void big_finish(const BigState *bs, BNode *bn, uint32_t *n_nodes, uint32_t nb) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb || !bs[j].split) return;
+    const BigState &s = bs[j];
+    const uint32_t base = atomicAdd(n_nodes, 2u);
+    BNode a, b;
+    for (int q = 0; q < 3; q++) { a.lo[q] = funkey(s.ckey[0][q]); a.hi[q] = funkey(s.ckey[0][3 + q]); b.lo[q] = funkey(s.ckey[1][q]); b.hi[q] = funkey(s.ckey[1][3 + q]); }
+    a.first = s.first; a.n = s.k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
+    b.first = s.first + s.k; b.n = s.n - s.k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
+    bn[base] = a; bn[base + 1] = b;
+    bn[s.node].left = base;
+}
+
 __global__ void sizes_level(BNode *bn, uint32_t begin, uint32_t end) {              // bottom-up: |desc(X)|
     for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
         const uint32_t l = bn[i].left;
@@ -332,10 +655,13 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     Proxy *d_px[2] = {nullptr, nullptr};
     BNode *d_bn = nullptr;
     MiptNode *d_nodes = nullptr;
-    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_cnt = nullptr, *d_root = nullptr;
+    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_cnt = nullptr, *d_root = nullptr, *d_ids = nullptr, *d_cbeg = nullptr;
+    BigState *d_big = nullptr;
+    ChunkInfo *d_chunks = nullptr;
+    const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
-        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_cnt, d_root};
+        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_cnt, d_root, d_ids, d_cbeg, d_big, d_chunks};
         for (void *q : p) if (q) (void)hipFree(q);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -353,6 +679,10 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_cnt, 4));
     HIP_TRY(hipMalloc((void **)&d_root, 24));
+    HIP_TRY(hipMalloc((void **)&d_ids, (size_t)big_cap * 4));
+    HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&d_big, (size_t)big_cap * sizeof(BigState)));
+    HIP_TRY(hipMalloc((void **)&d_chunks, (size_t)chunk_cap * sizeof(ChunkInfo)));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
@@ -366,9 +696,49 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     std::vector<uint32_t> lvl_begin;
     uint32_t begin = 0, end = 1;
     int cur = 0;
-    while (begin < end) {                               // one launch per tree level; every level strictly grows `end` or stops
+    bool may_have_big = n_tris > kBig;
+    std::vector<BNode> hbn;
+    while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
+        if (may_have_big) {                             // top of the tree: nodes too large for one workgroup
+            hbn.resize(end - begin);
+            HIP_TRY(hipMemcpy(hbn.data(), d_bn + begin, (size_t)(end - begin) * sizeof(BNode), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> ids, cbeg;
+            std::vector<ChunkInfo> chunks;
+            for (uint32_t i = 0; i < end - begin; i++) {
+                if (hbn[i].n <= kBig) continue;
+                cbeg.push_back((uint32_t)chunks.size());
+                for (uint32_t off = 0; off < hbn[i].n; off += kChunk) {
+                    ChunkInfo c{};
+                    c.big = (uint32_t)ids.size(); c.off = off; c.len = hbn[i].n - off < kChunk ? hbn[i].n - off : kChunk;
+                    chunks.push_back(c);
+                }
+                ids.push_back(begin + i);
+            }
+            cbeg.push_back((uint32_t)chunks.size());
+            const uint32_t nb = (uint32_t)ids.size(), nc = (uint32_t)chunks.size();
+            if (nb == 0) may_have_big = false;
+            else {
+                if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
+                HIP_TRY(hipMemcpy(d_ids, ids.data(), nb * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(d_cbeg, cbeg.data(), (nb + 1) * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(d_chunks, chunks.data(), (size_t)nc * sizeof(ChunkInfo), hipMemcpyHostToDevice));
+                const dim3 gb((nb + 63) / 64), tb(64);
+                hipLaunchKernelGGL(big_init, gb, tb, 0, nullptr, d_big, d_bn, d_ids, nb);
+                hipLaunchKernelGGL(big_range, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
+                hipLaunchKernelGGL(big_planes, dim3((nb * 3 + 63) / 64), tb, 0, nullptr, d_big, nb);
+                hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
+                hipLaunchKernelGGL(big_choose, gb, tb, 0, nullptr, d_big, nb);
+                hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
+                hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
+                hipLaunchKernelGGL(big_scan, gb, tb, 0, nullptr, d_big, d_chunks, d_cbeg, nb);
+                hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_hp, d_tp);
+                hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp);
+                hipLaunchKernelGGL(big_finish, gb, tb, 0, nullptr, d_big, d_bn, d_cnt, nb);
+            }
+        }
         hipLaunchKernelGGL(build_level, dim3(end - begin), dim3(kT), 0, nullptr, d_bn, begin, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_cnt);
+        hipLaunchKernelGGL(build_level_tiny, dim3((end - begin + 255) / 256), dim3(256), 0, nullptr, d_bn, begin, end, d_px[cur], d_px[cur ^ 1], d_cnt);
         HIP_TRY(hipGetLastError());
         uint32_t total = 0;
         HIP_TRY(hipMemcpy(&total, d_cnt, 4, hipMemcpyDeviceToHost));
