@@ -75,6 +75,15 @@ def test_validation_errors_without_gpu(rrt):
     d = L.MiptSceneDesc(L.ptr(tris), 2, L.ptr(nodes), 1, L.ptr(mats), 1, None, 0)
     assert lib.mipt_scene_create(C.byref(d), 0, C.byref(h)) == L.ERR_INVALID_ARG
     assert b"material_id" in lib.mipt_last_error()
+    # bounds beyond 2^40 (or non-finite) are outside the exact-division fast path's guard: rejected at upload
+    tris["material_id"] = 0
+    nodes = np.zeros(1, dtype=NODE)
+    nodes[0]["num_tris"] = 2
+    nodes[0]["bounds_max"] = (1e13, 1.0, 1.0)
+    d = L.MiptSceneDesc(L.ptr(tris), 2, L.ptr(nodes), 1, L.ptr(mats), 1, None, 0)
+    assert lib.mipt_scene_create(C.byref(d), 0, C.byref(h)) == L.ERR_SCENE_LIMIT
+    nodes[0]["bounds_max"] = (np.inf, 1.0, 1.0)
+    assert lib.mipt_scene_create(C.byref(d), 0, C.byref(h)) == L.ERR_SCENE_LIMIT
     # render entry points reject null scenes / bad options with the reference's messages (renderer.rs:15-26)
     opt = rrt.make_options(0, 10, 1, 1)
     assert lib.mipt_render(None, None, C.byref(opt), None, None, None) == L.ERR_INVALID_ARG

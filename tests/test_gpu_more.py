@@ -564,3 +564,67 @@ def test_device_bvh_builder_random_soups(rrt):
         for k in ("bounds_min", "bounds_max"):
             a[k] += np.float32(0); b[k] += np.float32(0)
         assert a.tobytes() == b.tobytes(), it
+
+
+def _chain_bvh(rrt, depth):
+    """Hand-built BVH (the ABI accepts any well-formed tree): a chain in which every inner node has a FAR leaf child and a
+    NEAR inner child for a ray along +x, so each level pushes one stack entry: stack occupancy = depth."""
+    from rust_ray_tracing_amd import NODE, TRIANGLE
+    n = depth + 1
+    tris = np.zeros(n, dtype=TRIANGLE)
+    xs = 1000.0 - np.arange(n, dtype=np.float32) * 2.0                    # triangle k sits at x = 1000 - 2k (far side first)
+    for k in range(n):
+        tris["vertices"]["position"][k] = [(xs[k], -1, -1), (xs[k], 1, -1), (xs[k], 0, 1)]
+    tris["vertices"]["normal"] = (-1, 0, 0)
+    nodes = np.zeros(2 * n - 1, dtype=NODE)
+
+    def box(lo, hi):
+        return (lo, -1.0, -1.0), (hi, 1.0, 1.0)
+    nodes[0]["bounds_min"], nodes[0]["bounds_max"] = box(xs[-1], xs[0])
+    nodes[0]["first_tri_or_child"] = 1
+    for k in range(n - 1):                                                # children of inner node k at 2k+1 (leaf k), 2k+2 (rest)
+        leaf, rest = 2 * k + 1, 2 * k + 2
+        nodes[leaf]["bounds_min"], nodes[leaf]["bounds_max"] = box(xs[k], xs[k])
+        nodes[leaf]["first_tri_or_child"], nodes[leaf]["num_tris"] = k, 1
+        nodes[rest]["bounds_min"], nodes[rest]["bounds_max"] = box(xs[-1], xs[k + 1])
+        if k == n - 2:
+            nodes[rest]["first_tri_or_child"], nodes[rest]["num_tris"] = k + 1, 1
+        else:
+            nodes[rest]["first_tri_or_child"], nodes[rest]["num_tris"] = 2 * k + 3, 0
+    sc = rrt.Scene.from_arrays(tris, [rrt.material_default()], build_bvh=False)
+    sc.bvh_nodes = nodes
+    sc.set_camera(rrt.Camera(position=(0.0, 0.0, 0.0), pitch=0.0, yaw=180.0))   # rays travel along -forward = +x
+    return sc
+
+
+def test_stack_spill_region_and_overflow_reporting(rrt, orc):
+    """Traversal-stack entries 17..64 live in HBM; beyond 64 the kernel reports MIPT_ERR_STACK (the reference panics at 32)."""
+    from rust_ray_tracing_amd import _lib as L
+    sc = _chain_bvh(rrt, 60)                                               # needs ~60 pending entries: inside the capacity
+    hdr, rgba, st = _render(rrt, sc, 32, 32, 2, 4)
+    ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), [], sc.camera.uniform, 32, 32, 2, 4)
+    assert st["max_stack"] == rst["max_stack"] and st["max_stack"] > 40 and rst["stack_overflows"] == 0
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
+    deep = _chain_bvh(rrt, 120)                                            # overflows both the kernel's 64 and the oracle's 64
+    r = rrt.Renderer.new(rrt.RendererOptions(samples=1, max_ray_depth=2, output_image_dimensions=(16, 16), output_image_path="/dev/null"))
+    with pytest.raises(rrt.MiptError) as e:
+        r.render_buffers(deep)
+    assert e.value.code == L.ERR_STACK
+    _, _, ost = orc.render(deep.tris, deep.bvh_nodes, deep.materials_array(), [], deep.camera.uniform, 16, 16, 1, 2)
+    assert ost["stack_overflows"] > 0
+
+
+def test_negative_uv_is_clamped_and_counted(rrt, orc):
+    """Texture::color_at panics on negative uv (texture.rs:33-38, SURVEY T10); kernel and oracle clamp the index identically
+    and count the event."""
+    from rust_ray_tracing_amd import synth
+    tris, mats, texs, cam = synth.make_scene("helmet", n_target=2000, tex_size=16)
+    tris["vertices"]["tex_coord_x"] -= 3.3
+    tris["vertices"]["tex_coord_y"] -= 1.7
+    sc = rrt.Scene.from_arrays(tris, mats, texs)
+    sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    r = rrt.Renderer.new(rrt.RendererOptions(samples=2, max_ray_depth=6, output_image_dimensions=(64, 36), output_image_path="/dev/null"))
+    hdr, rgba, st = r.render_buffers(sc, flags=rrt.FLAG_COUNT)
+    ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, 64, 36, 2, 6)
+    assert st["tex_clamped"] == rst["tex_clamped"] and st["tex_clamped"] > 0
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgba, ref_rgba)
