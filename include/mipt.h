@@ -205,6 +205,13 @@ int  mipt_obj_load(const char *path, MiptObj **out);
 int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
 void mipt_obj_free(MiptObj *obj);
 
+/* Texture::load (src/texture.rs:13-31): decodes an image file (PNG, JPEG or binary PPM, chosen by extension like
+ * image::open), flips it vertically and expands to RGBA8; hash_out (may be NULL) receives the djb2 hash the loader
+ * de-duplicates textures by (texture.rs:40-48).  desc_out borrows the image's pixels until mipt_texture_free. */
+typedef struct MiptImage MiptImage;
+int  mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out);
+void mipt_texture_free(MiptImage *img);
+
 /* The same build on the GPU (level-synchronous binned SAH with the partition's closed-form permutation); identical output
  * (sign of zero in a bound aside).  Uploads `tris`, downloads the reordered triangles and the nodes; build_ms_out (may be
  * NULL) receives the device time of the build itself without the transfers. */

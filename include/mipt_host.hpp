@@ -40,7 +40,23 @@ struct Camera {                                            // src/scene.rs:169-1
     void update_view() { mipt_camera_from_pose(position, pitch, yaw, &uniform); }
 };
 
-struct Texture { uint32_t width = 0, height = 0; std::vector<uint8_t> pixel_data; };   // src/texture.rs:4-10
+struct Texture {                                           // src/texture.rs:4-10
+    uint32_t width = 0, height = 0, hash = 0;
+    std::vector<uint8_t> pixel_data;                       // RGBA8, rows as Texture::load stores them (flipv applied)
+    static std::optional<Texture> load(const std::string &path) {   // src/texture.rs:13-31
+        MiptImage *img = nullptr;
+        MiptTexture d{};
+        Texture t;
+        if (mipt_texture_load(path.c_str(), &img, &d, &t.hash) != MIPT_OK) {
+            log_error(mipt_last_error());
+            return std::nullopt;
+        }
+        t.width = d.width; t.height = d.height;
+        t.pixel_data.assign(d.rgba8, d.rgba8 + (size_t)d.width * d.height * 4);
+        mipt_texture_free(img);
+        return t;
+    }
+};
 
 class Scene {                                              // src/scene.rs:12-19
   public:

@@ -73,6 +73,7 @@ EXPORTS = [
     "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_postprocess_device", "mipt_bvh_build", "mipt_bvh_build_device",
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
     "mipt_device_count", "mipt_debug_eval", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
+    "mipt_texture_load", "mipt_texture_free",
 ]
 
 _lib = None
@@ -132,6 +133,10 @@ def load() -> C.CDLL:
     lib.mipt_obj_free.restype = None
     lib.mipt_obj_get.argtypes = [vp, C.POINTER(MiptSceneDesc), C.POINTER(C.POINTER(C.c_char_p))]
     lib.mipt_obj_get.restype = C.c_int
+    lib.mipt_texture_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(MiptTexture), C.POINTER(u32)]
+    lib.mipt_texture_load.restype = C.c_int
+    lib.mipt_texture_free.argtypes = [vp]
+    lib.mipt_texture_free.restype = None
     _lib = lib
     return lib
 

@@ -8,8 +8,9 @@
 // Deviations, both documented in DESIGN.md:
 //  * materials keep INSERTION order (the reference iterates a HashMap, so its material ids are
 //    a per-process random permutation -- src/loader/obj.rs:81-90; results are unaffected);
-//  * map_* texture lines need an image decoder (the `image` crate, not vendored): PNG (png_decode.cpp) and
-//    binary PPM (P6) files are decoded here; other formats (JPEG ...) are reported and skipped.
+//  * map_* texture lines need an image decoder (the `image` crate, not vendored): PNG (png_decode.cpp), JPEG
+//    (jpeg_decode.cpp) and binary PPM (P6) files are decoded here, chosen by file extension as image::open does;
+//    other formats are reported and skipped.
 #include "../../include/mipt.h"
 
 #include <array>
@@ -25,6 +26,7 @@
 
 void mipt_internal_set_error(const char *msg);   // mipt_api.cpp: feeds mipt_last_error()
 namespace mipt_png { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
+namespace mipt_jpeg { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
 
 namespace {
 
@@ -138,10 +140,10 @@ bool load_ppm(const std::string &path, Tex *t) {
     return true;
 }
 
-// Texture::load for PNG: decode, flipv(), RGBA8 (texture.rs:18)
-bool load_png(const std::string &path, Tex *t, std::string *err) {
+// Texture::load for PNG / JPEG: decode, flipv(), RGBA8 (texture.rs:18)
+bool load_decoded(const std::string &path, bool jpeg, Tex *t, std::string *err) {
     std::vector<uint8_t> top_down;
-    if (!mipt_png::decode(path, &t->w, &t->h, &top_down, err)) return false;
+    if (!(jpeg ? mipt_jpeg::decode(path, &t->w, &t->h, &top_down, err) : mipt_png::decode(path, &t->w, &t->h, &top_down, err))) return false;
     t->rgba.resize(top_down.size());
     const size_t row = (size_t)t->w * 4;
     for (uint32_t y = 0; y < t->h; y++) memcpy(&t->rgba[(size_t)y * row], &top_down[(size_t)(t->h - 1 - y) * row], row);
@@ -149,14 +151,26 @@ bool load_png(const std::string &path, Tex *t, std::string *err) {
     return true;
 }
 
+// Texture::load (texture.rs:13-31): the decoder is chosen by extension, as image::open does
+bool load_any_texture(const std::string &path, Tex *t, std::string *err) {
+    std::string ext;
+    const size_t dot = path.find_last_of('.');
+    if (dot != std::string::npos)
+        for (size_t i = dot + 1; i < path.size(); i++) ext += (char)tolower((unsigned char)path[i]);
+    if (ext == "png") return load_decoded(path, false, t, err);
+    if (ext == "jpg" || ext == "jpeg") return load_decoded(path, true, t, err);
+    if (load_ppm(path, t)) return true;
+    *err = "only PNG, JPEG and binary PPM (P6) are decoded in this build";
+    return false;
+}
+
 // obj.rs:267-309
 void load_texture(const std::string &path, MiptObj *obj, uint32_t *slot) {
     Tex t;
     std::string err;
-    const bool is_png = path.size() > 4 && (path.compare(path.size() - 4, 4, ".png") == 0 || path.compare(path.size() - 4, 4, ".PNG") == 0);
-    if (!(is_png ? load_png(path, &t, &err) : load_ppm(path, &t))) {
-        // Texture::load returns None when the file is missing (texture.rs:14-17); undecodable formats are skipped too
-        fprintf(stderr, "[mipt] texture '%s' skipped: %s\n", path.c_str(), is_png ? err.c_str() : "only PNG and binary PPM (P6) are decoded in this build (no JPEG)");
+    if (!load_any_texture(path, &t, &err)) {
+        // Texture::load returns None when the file is missing (texture.rs:14-17); undecodable files are skipped too
+        fprintf(stderr, "[mipt] texture '%s' skipped: %s\n", path.c_str(), err.c_str());
         return;
     }
     for (size_t i = 0; i < obj->textures.size(); i++)
@@ -393,5 +407,23 @@ int mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc, const char ***material_names
 }
 
 void mipt_obj_free(MiptObj *obj) { delete obj; }
+
+struct MiptImage { Tex t; };
+
+int mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out) {
+    if (!path || !out || !desc_out) return fail("mipt_texture_load: null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(std::string("Could not find texture at path: '") + path + "'");          // texture.rs:14-17
+    fclose(f);
+    MiptImage *img = new MiptImage();
+    std::string err;
+    if (!load_any_texture(path, &img->t, &err)) { delete img; return fail(std::string("texture '") + path + "': " + err); }
+    desc_out->width = img->t.w; desc_out->height = img->t.h; desc_out->rgba8 = img->t.rgba.data();
+    if (hash_out) *hash_out = img->t.hash;
+    *out = img;
+    return MIPT_OK;
+}
+void mipt_texture_free(MiptImage *img) { delete img; }
 
 } // extern "C"

@@ -77,6 +77,29 @@ def material_default() -> np.ndarray:  # scene.rs:148-167
     return m
 
 
+@dataclass
+class Texture:  # texture.rs:3-10
+    width: int
+    height: int
+    hash: int
+    pixel_data: np.ndarray          # (height, width, 4) uint8, rows as Texture::load stores them (flipv applied)
+
+    @staticmethod
+    def load(path: str) -> Optional["Texture"]:  # texture.rs:13-31 (None + log line when the file is missing / undecodable)
+        lib = L.load()
+        img = C.c_void_p()
+        desc = L.MiptTexture()
+        h = C.c_uint32()
+        if lib.mipt_texture_load(os.fsencode(path), C.byref(img), C.byref(desc), C.byref(h)) != 0:
+            log_error(lib.mipt_last_error().decode())
+            return None
+        try:
+            px = np.ctypeslib.as_array(C.cast(desc.rgba8, C.POINTER(C.c_uint8)), (desc.height, desc.width, 4)).copy()
+            return Texture(int(desc.width), int(desc.height), int(h.value), px)
+        finally:
+            lib.mipt_texture_free(img)
+
+
 class Scene:  # scene.rs:12-19
     """tris / materials / textures / bvh / camera.  ``materials`` is name -> Material in id order."""
 

@@ -21,6 +21,7 @@ int main(int argc, char **argv) {
     { auto b = o; b.is_realtime = true; CHECK(!Renderer::create(b)); }
     { RendererOptions d; CHECK(d.samples == 1 && d.max_ray_depth == 6 && d.output_image_dimensions.first == 1920 && d.is_realtime); }
     CHECK(!Scene::load("/nonexistent/scene.obj"));
+    CHECK(!Texture::load("/nonexistent/tex.png"));                                       // texture.rs:14-17
     auto scene = Scene::load(obj);
     CHECK(scene && scene->tris.size() == 12 && scene->materials.size() == 4 && scene->materials[3].first == "light");
     CHECK(scene->bvh_nodes.size() % 2 == 1 && scene->bvh_nodes.size() <= 23);

@@ -36,7 +36,7 @@ def test_cpp_host_mirror_renders_config1(built, tmp_path):
 
 
 def test_host_code_under_asan_ubsan(built, tmp_path):
-    """GPU sanitizers are unavailable: the host-side C++ that parses untrusted files (OBJ/MTL, PNG) and the BVH builder
+    """GPU sanitizers are unavailable: the host-side C++ that parses untrusted files (OBJ/MTL, PNG, JPEG) and the BVH builder
     run under AddressSanitizer + UBSan on the CPU, with truncated / bit-flipped inputs."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,8 +54,21 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
                            os.path.join(src, "bvh_build.cpp"), os.path.join(src, "obj_loader.cpp"), os.path.join(src, "png_decode.cpp"),
-                           os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe, "-lpthread"])
-    out = subprocess.run([exe, str(tmp_path), str(tmp_path / "tex.png")], capture_output=True, text=True,
+                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe, "-lpthread"])
+    jpegs = []
+    try:
+        from PIL import Image
+        from test_obj_loader import _jpeg_test_image
+        for i, kw in enumerate([dict(subsampling=2), dict(subsampling=1, progressive=True), dict(subsampling=0, restart_marker_blocks=2)]):
+            p = str(tmp_path / f"j{i}.jpg")
+            try:
+                Image.fromarray(_jpeg_test_image(29, 43)).save(p, "JPEG", quality=85, **kw)
+            except (TypeError, ValueError):
+                continue
+            jpegs.append(p)
+    except ImportError:
+        pass
+    out = subprocess.run([exe, str(tmp_path), str(tmp_path / "tex.png")] + jpegs, capture_output=True, text=True,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout + out.stderr[-3000:]
     assert "sanitize_host ok" in out.stdout

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 
 def test_cornell_obj_roundtrip(rrt, tmp_path):
@@ -143,3 +144,92 @@ def test_png_textures_all_colour_types_and_filters(rrt, tmp_path):
     (tmp_path / "rgba.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
     sc2 = rrt.Scene.load(str(tmp_path / "t.obj"))
     assert sc2 is not None and int(sc2.materials["m_rgba"]["base_color_tex_id"]) == 0xFFFFFFFF
+
+
+# ---- JPEG textures (jpeg_decode.cpp) -------------------------------------------------------------------------------
+def _jpeg_test_image(h, w, seed=1):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 5.0), 128 + 90 * np.cos(x / 11.0 + y / 3.0), (x * 3 + y * 5) % 256], -1)
+    return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+
+
+def _pil_rgb_flipped(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))[::-1]
+
+
+@pytest.mark.parametrize("size", [(64, 64), (37, 53), (1, 1), (8, 8), (17, 3), (3, 17), (2, 2), (5, 4), (100, 131)])
+def test_jpeg_decoder_matches_libjpeg_bit_for_bit(rrt, tmp_path, size):
+    """Texture::load on JPEG files (texture.rs:18) through the built-in decoder, against Pillow's libjpeg(-turbo) as the
+    known-answer source: baseline / progressive (incl. successive-approximation refinement scans) / optimised tables,
+    4:4:4 / 4:2:2 / 4:2:0 chroma with odd sizes (edge replication, the narrow-component upsampling rule), greyscale,
+    restart intervals, custom quantisation tables.  Whether the `image` crate rounds identically is not pinned."""
+    Image = pytest.importorskip("PIL.Image")
+    h, w = size
+    img = _jpeg_test_image(h, w)
+    n = 0
+    variants = [dict(), dict(progressive=True), dict(optimize=True), dict(quality=30), dict(quality=100), dict(progressive=True, quality=95),
+                dict(restart_marker_blocks=1), dict(restart_marker_rows=1, progressive=True), dict(qtables=[list(range(1, 65)), [3] * 64])]
+    for sub in (0, 1, 2):
+        for kw in variants:
+            p = str(tmp_path / f"t{n}.jpg"); n += 1
+            try:
+                Image.fromarray(img).save(p, "JPEG", subsampling=sub, **{"quality": 75, **kw})
+            except (TypeError, ValueError):                    # an encoder option this Pillow does not know
+                continue
+            t = rrt.Texture.load(p)
+            assert t is not None, (sub, kw)
+            ref = _pil_rgb_flipped(p)
+            assert (t.height, t.width) == ref.shape[:2]
+            assert np.array_equal(t.pixel_data[..., :3], ref), (sub, kw)
+            assert (t.pixel_data[..., 3] == 255).all()
+    for kw in (dict(), dict(progressive=True)):
+        p = str(tmp_path / f"g{n}.jpeg"); n += 1               # .jpeg extension, one component
+        Image.fromarray(img[..., 0]).save(p, "JPEG", quality=80, **kw)
+        t = rrt.Texture.load(p)
+        assert t is not None and np.array_equal(t.pixel_data[..., :3], _pil_rgb_flipped(p))
+
+
+def test_jpeg_real_files_when_present(rrt):
+    """Camera-made JPEGs that ship with Python packages in this image (not with the reference): same bit-for-bit check."""
+    pytest.importorskip("PIL.Image")
+    import glob
+    files = []
+    for pat in ("/usr/local/lib/python3*/dist-packages/sklearn/datasets/images/*.jpg",
+                "/usr/local/lib/python3*/dist-packages/matplotlib/mpl-data/sample_data/*.jpg"):
+        files += sorted(glob.glob(pat))
+    if not files:
+        pytest.skip("no sample JPEGs on this machine")
+    for f in files:
+        t = rrt.Texture.load(f)
+        assert t is not None, f
+        assert np.array_equal(t.pixel_data[..., :3], _pil_rgb_flipped(f)), f
+
+
+def test_jpeg_texture_through_obj_and_rejections(rrt, tmp_path, capfd):
+    Image = pytest.importorskip("PIL.Image")
+    img = _jpeg_test_image(24, 40, seed=3)
+    Image.fromarray(img).save(str(tmp_path / "kd.JPG"), "JPEG", quality=90, subsampling=2)
+    Image.fromarray(img).save(str(tmp_path / "same.jpg"), "JPEG", quality=90, subsampling=2)      # same pixels: de-duplicated by hash
+    Image.fromarray(np.dstack([img, img[..., :1]])).convert("CMYK").save(str(tmp_path / "cmyk.jpg"), "JPEG")
+    (tmp_path / "junk.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    (tmp_path / "t.mtl").write_text("newmtl a\nmap_Kd kd.JPG\n\nnewmtl b\nmap_Kd same.jpg\n\nnewmtl c\nmap_Kd cmyk.jpg\n\nnewmtl d\nmap_Kd junk.jpg\n")
+    (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\nusemtl b\nf 1 2 3\nusemtl c\nf 1 2 3\nusemtl d\nf 1 2 3\n")
+    sc = rrt.Scene.load(str(tmp_path / "t.obj"))
+    assert sc is not None and len(sc.textures) == 1
+    ta, tb = int(sc.materials["a"]["base_color_tex_id"]), int(sc.materials["b"]["base_color_tex_id"])
+    assert ta == tb == 0
+    assert np.array_equal(sc.textures[0][..., :3], _pil_rgb_flipped(str(tmp_path / "kd.JPG")))
+    assert int(sc.materials["c"]["base_color_tex_id"]) == 0xFFFFFFFF and int(sc.materials["d"]["base_color_tex_id"]) == 0xFFFFFFFF
+    assert "CMYK" in capfd.readouterr().err
+    # Texture::load on a missing file: the reference's log line, None
+    assert rrt.Texture.load(str(tmp_path / "nope.jpg")) is None
+    assert "Could not find texture at path" in capfd.readouterr().err
+    # the hash the loader de-duplicates by is djb2 over every 4th pixel word (texture.rs:40-48)
+    t = rrt.Texture.load(str(tmp_path / "kd.JPG"))
+    words = t.pixel_data.reshape(-1, 4).copy().view("<u4").reshape(-1)[::4]
+    hsh = 5381
+    for wd in words.tolist():
+        hsh = (hsh * 33 + wd) & 0xFFFFFFFF
+    assert hsh == t.hash
