@@ -1,9 +1,11 @@
-// png_decode.cpp -- minimal PNG reader for the OBJ/MTL loader's map_* textures.
+// png_decode.cpp -- PNG reader for the OBJ/MTL loader's map_* textures.
 // The reference decodes textures with the `image` crate (image::open(path).flipv().to_rgba8(), src/texture.rs:18),
-// which is not vendored; this restates the published PNG/zlib formats (RFC 2083, RFC 1950/1951): non-interlaced,
-// bit depth 8 (and 16, reduced to the high byte), colour types 0, 2, 3, 4, 6, all five scanline filters, tRNS for
-// palettes.  Output is RGBA8, top row first (the caller applies flipv).  No reference fixture pins the decoder:
-// "parity unpinned" for texel bytes; tests round-trip against Python's zlib.
+// which is not vendored; this restates the published PNG/zlib formats (RFC 2083, RFC 1950/1951): every colour type and
+// bit depth of the standard (grey 1/2/4/8/16, RGB 8/16, palette 1/2/4/8, grey+alpha and RGBA 8/16), all five scanline
+// filters, Adam7 interlacing, tRNS for palettes and as a colour key.  Output is RGBA8, top row first (the caller applies
+// flipv): low-depth grey is scaled to the full range and 16-bit samples are rounded, (x + 128) / 257, which is how the
+// `image` crate narrows u16 to u8 -- from its published behaviour, not checked against it here ("parity unpinned" for
+// 16-bit files; 8-bit and lower are lossless and checked against Pillow's decoder and Python's zlib in the tests).
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -166,51 +168,81 @@ bool decode(const std::string &path, uint32_t *w_out, uint32_t *h_out, std::vect
         pos += 12 + (size_t)len;
     }
     if (w == 0 || h == 0 || w > 65536 || h > 65536) { *err = "bad dimensions"; return false; }
-    if (interlace) { *err = "interlaced PNG is not supported"; return false; }
-    if (depth != 8 && depth != 16) { *err = "only bit depths 8 and 16 are supported"; return false; }
-    int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!channels || (ctype == 3 && depth != 8)) { *err = "unsupported colour type"; return false; }
+    if (interlace > 1) { *err = "unknown interlace method"; return false; }
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+    if (!channels || !depth_ok) { *err = "unsupported colour type / bit depth"; return false; }
     std::vector<uint8_t> raw;
     if (!inflate(idat.data(), idat.size(), raw)) { *err = "zlib stream is corrupt"; return false; }
-    const size_t bpp = (size_t)channels * depth / 8, stride = (size_t)w * bpp;
-    if (raw.size() < (stride + 1) * h) { *err = "image data too short"; return false; }
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    const size_t bits = (size_t)channels * depth, bpp = bits >= 8 ? bits / 8 : 1;       // filter unit: whole bytes, at least 1
+    // tRNS colour key for grey / RGB images: a pixel equal to it (at the file's bit depth) becomes transparent
+    bool has_key = false;
+    uint32_t key[3] = {0, 0, 0};
+    if (ctype == 0 && trns.size() >= 2) { has_key = true; key[0] = (uint32_t)trns[0] << 8 | trns[1]; }
+    if (ctype == 2 && trns.size() >= 6) { has_key = true; for (int k = 0; k < 3; k++) key[k] = (uint32_t)trns[2 * k] << 8 | trns[2 * k + 1]; }
+    // sample -> 8 bits as the `image` crate's to_rgba8 does: 1/2/4-bit grey scaled to the full range, 16 bit rounded ((x + 128) / 257)
+    auto to8 = [&](uint32_t v) -> uint8_t {
+        return depth == 16 ? (uint8_t)((v + 128u) / 257u) : depth == 8 ? (uint8_t)v : (uint8_t)(v * (255u / ((1u << depth) - 1u)));
+    };
     rgba->assign((size_t)w * h * 4, 255);
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t *row = &raw[(stride + 1) * y];
-        const int ft = row[0];
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = row[1 + i];
-            int v;
-            switch (ft) {
-            case 0: v = x; break;
-            case 1: v = x + a; break;
-            case 2: v = x + b; break;
-            case 3: v = x + ((a + b) >> 1); break;
-            case 4: v = x + paeth(a, b, c); break;
-            default: *err = "bad filter type"; return false;
+    // Adam7: seven reduced images, each filtered on its own; a non-interlaced file is the single pass (0, 0, 1, 1)
+    static const uint8_t px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+    size_t rp = 0;
+    std::vector<uint8_t> prev, cur;
+    for (int pass = 0; pass < (interlace ? 7 : 1); pass++) {
+        const uint32_t x0 = interlace ? px0[pass] : 0, y0 = interlace ? py0[pass] : 0, dx = interlace ? pdx[pass] : 1, dy = interlace ? pdy[pass] : 1;
+        if (x0 >= w || y0 >= h) continue;
+        const uint32_t pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+        const size_t stride = ((size_t)pw * bits + 7) / 8;
+        if (raw.size() < rp + (stride + 1) * ph) { *err = "image data too short"; return false; }
+        prev.assign(stride, 0); cur.assign(stride, 0);
+        for (uint32_t py = 0; py < ph; py++) {
+            const uint8_t *row = &raw[rp];
+            rp += stride + 1;
+            const int ft = row[0];
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = row[1 + i];
+                int v;
+                switch (ft) {
+                case 0: v = x; break;
+                case 1: v = x + a; break;
+                case 2: v = x + b; break;
+                case 3: v = x + ((a + b) >> 1); break;
+                case 4: v = x + paeth(a, b, c); break;
+                default: *err = "bad filter type"; return false;
+                }
+                cur[i] = (uint8_t)v;
             }
-            cur[i] = (uint8_t)v;
+            auto sample = [&](size_t k) -> uint32_t {            // k-th sample of the row, at the file's bit depth
+                if (depth == 16) return (uint32_t)cur[2 * k] << 8 | cur[2 * k + 1];
+                if (depth == 8) return cur[k];
+                const size_t bit = k * (size_t)depth;
+                return (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1u << depth) - 1u);
+            };
+            for (uint32_t px = 0; px < pw; px++) {
+                uint8_t *d = &(*rgba)[((size_t)(y0 + py * dy) * w + (x0 + px * dx)) * 4];
+                switch (ctype) {
+                case 0: { const uint32_t g = sample(px); d[0] = d[1] = d[2] = to8(g); if (has_key && g == key[0]) d[3] = 0; break; }
+                case 2: {
+                    const uint32_t r = sample((size_t)px * 3), g = sample((size_t)px * 3 + 1), b = sample((size_t)px * 3 + 2);
+                    d[0] = to8(r); d[1] = to8(g); d[2] = to8(b);
+                    if (has_key && r == key[0] && g == key[1] && b == key[2]) d[3] = 0;
+                    break;
+                }
+                case 3: {
+                    const size_t k = sample(px);
+                    if (k * 3 + 2 >= plte.size()) { *err = "palette index out of range"; return false; }
+                    d[0] = plte[k * 3]; d[1] = plte[k * 3 + 1]; d[2] = plte[k * 3 + 2];
+                    if (k < trns.size()) d[3] = trns[k];
+                    break;
+                }
+                case 4: d[0] = d[1] = d[2] = to8(sample((size_t)px * 2)); d[3] = to8(sample((size_t)px * 2 + 1)); break;
+                case 6: for (int k = 0; k < 4; k++) d[k] = to8(sample((size_t)px * 4 + k)); break;
+                }
+            }
+            prev.swap(cur);
         }
-        for (uint32_t x = 0; x < w; x++) {
-            const uint8_t *s = &cur[(size_t)x * bpp];
-            uint8_t *d = &(*rgba)[((size_t)y * w + x) * 4];
-            const size_t st = depth / 8;                         // 16-bit samples: keep the high byte
-            switch (ctype) {
-            case 0: d[0] = d[1] = d[2] = s[0]; break;
-            case 2: d[0] = s[0]; d[1] = s[st]; d[2] = s[2 * st]; break;
-            case 3: {
-                const size_t k = s[0];
-                if (k * 3 + 2 >= plte.size()) { *err = "palette index out of range"; return false; }
-                d[0] = plte[k * 3]; d[1] = plte[k * 3 + 1]; d[2] = plte[k * 3 + 2];
-                if (k < trns.size()) d[3] = trns[k];
-                break;
-            }
-            case 4: d[0] = d[1] = d[2] = s[0]; d[3] = s[st]; break;
-            case 6: d[0] = s[0]; d[1] = s[st]; d[2] = s[2 * st]; d[3] = s[3 * st]; break;
-            }
-        }
-        prev.swap(cur);
     }
     *w_out = w; *h_out = h;
     return true;

@@ -233,3 +233,120 @@ def test_jpeg_texture_through_obj_and_rejections(rrt, tmp_path, capfd):
     for wd in words.tolist():
         hsh = (hsh * 33 + wd) & 0xFFFFFFFF
     assert hsh == t.hash
+
+
+# ---- PNG: every colour type / bit depth, Adam7, colour keys ----------------------------------------------------------
+def _png_general(path, samples, ctype, depth, interlace=False, palette=None, trns=None):
+    """samples: (h, w, channels) integers at `depth` bits.  Packs, (Adam7-)splits, filters (types cycle 0..4), deflates."""
+    import struct
+    import zlib
+    h, w, ch_n = samples.shape
+
+    def pack_rows(img):                                     # img (ph, pw, ch) -> list of packed byte rows
+        ph, pw, _ = img.shape
+        flat = img.reshape(ph, pw * ch_n).astype(np.uint32)
+        if depth == 16:
+            return [np.stack([r >> 8, r & 255], -1).astype(np.uint8).reshape(-1) for r in flat]
+        if depth == 8:
+            return [r.astype(np.uint8) for r in flat]
+        per = 8 // depth
+        out = []
+        for r in flat:
+            pad = (-len(r)) % per
+            rr = np.concatenate([r, np.zeros(pad, np.uint32)]).reshape(-1, per)
+            shifts = np.array([8 - depth * (k + 1) for k in range(per)], np.uint32)
+            out.append((rr << shifts).sum(1).astype(np.uint8))
+        return out
+
+    bpp = max(1, ch_n * depth // 8)
+    raw = bytearray()
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)] if interlace else [(0, 0, 1, 1)]
+    n = 0
+    for x0, y0, dx, dy in passes:
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for row in pack_rows(sub):
+            cur = row.astype(np.int32)
+            pv = np.zeros_like(cur) if prev is None else prev
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            c = np.concatenate([np.zeros(bpp, np.int32), pv[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            ft = n % 5
+            n += 1
+            if ft == 0: enc = cur
+            elif ft == 1: enc = cur - a
+            elif ft == 2: enc = cur - pv
+            elif ft == 3: enc = cur - ((a + pv) >> 1)
+            else:
+                p = a + pv - c
+                pa, pb, pc = np.abs(p - a), np.abs(p - pv), np.abs(p - c)
+                enc = cur - np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, pv, c))
+            raw.append(ft)
+            raw += (enc & 255).astype(np.uint8).tobytes()
+            prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    out += chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_every_colour_type_and_depth(rrt, tmp_path, interlace):
+    """All 15 colour-type / bit-depth combinations of the PNG standard, plain and Adam7-interlaced, odd sizes (so that some
+    Adam7 passes are empty or one pixel wide), tRNS as a palette alpha table and as a grey / RGB colour key.  Depths <= 8
+    are checked against Pillow's decoder, 16-bit against the (x + 128) / 257 narrowing of the `image` crate."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11 + interlace)
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}
+    n = 0
+    for (h, w) in [(13, 21), (1, 1), (2, 3), (5, 1), (9, 8)]:
+        for ctype, depths in [(0, (1, 2, 4, 8, 16)), (2, (8, 16)), (3, (1, 2, 4, 8)), (4, (8, 16)), (6, (8, 16))]:
+            for depth in depths:
+                smp = rng.integers(0, 1 << depth, (h, w, ch[ctype]))
+                pal = trns = None
+                if ctype == 3:
+                    pal = rng.integers(0, 256, 3 << depth).astype(np.uint8)
+                    trns = rng.integers(0, 256, max(1, (1 << depth) // 2)).astype(np.uint8)
+                elif ctype == 0:
+                    k = int(smp[0, 0, 0]); trns = [k >> 8, k & 255]
+                elif ctype == 2:
+                    trns = [b for v in smp[0, 0] for b in (int(v) >> 8, int(v) & 255)]
+                p = str(tmp_path / f"p{n}.png"); n += 1
+                _png_general(p, smp, ctype, depth, interlace=interlace, palette=pal, trns=trns)
+                t = rrt.Texture.load(p)
+                assert t is not None, (h, w, ctype, depth)
+                got = t.pixel_data[::-1]
+                # expectation from the standard: low-depth grey scaled to the full range, 16 bit rounded, key compared at file depth
+                if depth == 16:
+                    s8 = ((smp.astype(np.uint32) + 128) // 257).astype(np.uint8)
+                elif depth == 8 or ctype == 3:
+                    s8 = smp.astype(np.uint8)
+                else:
+                    s8 = (smp * (255 // ((1 << depth) - 1))).astype(np.uint8)
+                want = np.full((h, w, 4), 255, np.uint8)
+                if ctype == 0:
+                    want[..., :3] = s8[..., :1]; want[..., 3] = np.where(smp[..., 0] == smp[0, 0, 0], 0, 255)
+                elif ctype == 2:
+                    want[..., :3] = s8; want[..., 3] = np.where((smp == smp[0, 0]).all(-1), 0, 255)
+                elif ctype == 3:
+                    idx = smp[..., 0]
+                    want[..., :3] = pal.reshape(-1, 3)[idx]
+                    want[..., 3] = np.concatenate([trns, np.full((1 << depth) - len(trns), 255, np.uint8)])[idx]
+                elif ctype == 4:
+                    want[..., :3] = s8[..., :1]; want[..., 3] = s8[..., 1]
+                else:
+                    want = s8
+                assert np.array_equal(got, want), (h, w, ctype, depth, interlace)
+                # Pillow as a second opinion where its conversion follows the standard too (it narrows 16 bit differently
+                # and compares a low-depth grey key after scaling)
+                if depth == 8 or ctype == 3:
+                    assert np.array_equal(got, np.asarray(Image.open(p).convert("RGBA"))), (h, w, ctype, depth, interlace)
+                elif depth < 8:
+                    assert np.array_equal(got[..., :3], np.asarray(Image.open(p).convert("RGB"))), (h, w, ctype, depth, interlace)
