@@ -205,7 +205,7 @@ int  mipt_obj_load(const char *path, MiptObj **out);
 int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
 void mipt_obj_free(MiptObj *obj);
 
-/* Texture::load (src/texture.rs:13-31): decodes an image file (PNG, JPEG or binary PPM, chosen by extension like
+/* Texture::load (src/texture.rs:13-31): decodes an image file (PNG, JPEG, TGA, BMP or binary PPM, chosen by extension like
  * image::open), flips it vertically and expands to RGBA8; hash_out (may be NULL) receives the djb2 hash the loader
  * de-duplicates textures by (texture.rs:40-48).  desc_out borrows the image's pixels until mipt_texture_free. */
 typedef struct MiptImage MiptImage;

@@ -9,7 +9,7 @@
 //  * materials keep INSERTION order (the reference iterates a HashMap, so its material ids are
 //    a per-process random permutation -- src/loader/obj.rs:81-90; results are unaffected);
 //  * map_* texture lines need an image decoder (the `image` crate, not vendored): PNG (png_decode.cpp), JPEG
-//    (jpeg_decode.cpp) and binary PPM (P6) files are decoded here, chosen by file extension as image::open does;
+//    (jpeg_decode.cpp), TGA / BMP (tga_bmp_decode.cpp) and binary PPM (P6) files are decoded here, chosen by file extension as image::open does;
 //    other formats are reported and skipped.
 #include "../../include/mipt.h"
 
@@ -27,6 +27,10 @@
 void mipt_internal_set_error(const char *msg);   // mipt_api.cpp: feeds mipt_last_error()
 namespace mipt_png { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
 namespace mipt_jpeg { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
+namespace mipt_img {
+bool decode_tga(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err);
+bool decode_bmp(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err);
+}
 
 namespace {
 
@@ -140,10 +144,18 @@ bool load_ppm(const std::string &path, Tex *t) {
     return true;
 }
 
-// Texture::load for PNG / JPEG: decode, flipv(), RGBA8 (texture.rs:18)
-bool load_decoded(const std::string &path, bool jpeg, Tex *t, std::string *err) {
+// Texture::load for the decoded formats: decode, flipv(), RGBA8 (texture.rs:18)
+enum class ImgFmt { Png, Jpeg, Tga, Bmp };
+bool load_decoded(const std::string &path, ImgFmt fmt, Tex *t, std::string *err) {
     std::vector<uint8_t> top_down;
-    if (!(jpeg ? mipt_jpeg::decode(path, &t->w, &t->h, &top_down, err) : mipt_png::decode(path, &t->w, &t->h, &top_down, err))) return false;
+    bool ok = false;
+    switch (fmt) {
+    case ImgFmt::Png: ok = mipt_png::decode(path, &t->w, &t->h, &top_down, err); break;
+    case ImgFmt::Jpeg: ok = mipt_jpeg::decode(path, &t->w, &t->h, &top_down, err); break;
+    case ImgFmt::Tga: ok = mipt_img::decode_tga(path, &t->w, &t->h, &top_down, err); break;
+    case ImgFmt::Bmp: ok = mipt_img::decode_bmp(path, &t->w, &t->h, &top_down, err); break;
+    }
+    if (!ok) return false;
     t->rgba.resize(top_down.size());
     const size_t row = (size_t)t->w * 4;
     for (uint32_t y = 0; y < t->h; y++) memcpy(&t->rgba[(size_t)y * row], &top_down[(size_t)(t->h - 1 - y) * row], row);
@@ -157,10 +169,12 @@ bool load_any_texture(const std::string &path, Tex *t, std::string *err) {
     const size_t dot = path.find_last_of('.');
     if (dot != std::string::npos)
         for (size_t i = dot + 1; i < path.size(); i++) ext += (char)tolower((unsigned char)path[i]);
-    if (ext == "png") return load_decoded(path, false, t, err);
-    if (ext == "jpg" || ext == "jpeg") return load_decoded(path, true, t, err);
+    if (ext == "png") return load_decoded(path, ImgFmt::Png, t, err);
+    if (ext == "jpg" || ext == "jpeg") return load_decoded(path, ImgFmt::Jpeg, t, err);
+    if (ext == "tga") return load_decoded(path, ImgFmt::Tga, t, err);
+    if (ext == "bmp") return load_decoded(path, ImgFmt::Bmp, t, err);
     if (load_ppm(path, t)) return true;
-    *err = "only PNG, JPEG and binary PPM (P6) are decoded in this build";
+    *err = "only PNG, JPEG, TGA, BMP and binary PPM (P6) are decoded in this build";
     return false;
 }
 

@@ -1,6 +1,6 @@
-// ASan/UBSan build of the host-side C++ (BVH builder, OBJ/MTL loader, PNG and JPEG decoders) -- GPU sanitizers are unavailable on
+// ASan/UBSan build of the host-side C++ (BVH builder, OBJ/MTL loader, PNG / JPEG / TGA / BMP decoders) -- GPU sanitizers are unavailable on
 // the pool, so memory safety of everything that parses untrusted files is checked on the CPU build:
-//   g++ -fsanitize=address,undefined bvh_build.cpp obj_loader.cpp png_decode.cpp jpeg_decode.cpp sanitize_host.cpp
+//   g++ -fsanitize=address,undefined bvh_build.cpp obj_loader.cpp png_decode.cpp jpeg_decode.cpp tga_bmp_decode.cpp sanitize_host.cpp
 // Feeds the loader valid files, truncated files and bit-flipped PNGs / JPEGs; builds BVHs over random soups.
 #include "mipt.h"
 
@@ -17,6 +17,10 @@ void mipt_internal_set_error(const char *m) { g_err = m ? m : ""; }
 extern "C" void mipt_material_default(MiptMaterial *m) { memset(m, 0, sizeof *m); m->base_color = {0.8f, 0.8f, 0.8f}; m->base_color_tex_id = m->emission_tex_id = UINT32_MAX; }
 namespace mipt_png { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
 namespace mipt_jpeg { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
+namespace mipt_img {
+bool decode_tga(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *);
+bool decode_bmp(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *);
+}
 
 int main(int argc, char **argv) {
     if (argc < 3) return 2;
@@ -41,7 +45,7 @@ int main(int argc, char **argv) {
         uint32_t w, h; std::vector<uint8_t> px; std::string err;
         if (mipt_png::decode(p, &w, &h, &px, &err)) { decoded++; if (px.size() != (size_t)w * h * 4) return 3; } else rejected++;
     }
-    // 2b. the same for every JPEG the test wrote (baseline / progressive / subsampled / restart markers)
+    // 2b. the same for every JPEG / TGA / BMP the test wrote
     int jdecoded = 0, jrejected = 0;
     for (int a = 3; a < argc; a++) {
         std::ifstream jf(argv[a], std::ios::binary);
@@ -52,10 +56,13 @@ int main(int argc, char **argv) {
             if (it == 0) {}                                             // the intact file must decode
             else if (it % 3 == 0) m.resize(rng() % (jgood.size() + 1));
             else for (int k = 0; k < 1 + (int)(rng() % 6); k++) m[rng() % m.size()] ^= (uint8_t)(1u << (rng() % 8));
-            const std::string p = dir + "/mut.jpg";
+            const std::string name = argv[a];
+            const bool tga = name.size() > 4 && name.compare(name.size() - 4, 4, ".tga") == 0, bmp = name.size() > 4 && name.compare(name.size() - 4, 4, ".bmp") == 0;
+            const std::string p = dir + "/mut.bin";
             { std::ofstream o(p, std::ios::binary); o.write((const char *)m.data(), (std::streamsize)m.size()); }
             uint32_t w = 0, h = 0; std::vector<uint8_t> px; std::string err;
-            if (mipt_jpeg::decode(p, &w, &h, &px, &err)) { jdecoded++; if (px.size() != (size_t)w * h * 4) return 6; } else { jrejected++; if (it == 0) return 7; }
+            const bool ok = tga ? mipt_img::decode_tga(p, &w, &h, &px, &err) : bmp ? mipt_img::decode_bmp(p, &w, &h, &px, &err) : mipt_jpeg::decode(p, &w, &h, &px, &err);
+            if (ok) { jdecoded++; if (px.size() != (size_t)w * h * 4) return 6; } else { jrejected++; if (it == 0) return 7; }
         }
     }
     // 3. BVH builder over random soups (threads on)
@@ -67,7 +74,7 @@ int main(int argc, char **argv) {
         uint32_t cnt = 0;
         if (mipt_bvh_build(t.data(), n, nodes.data(), 2 * n, &cnt, 4) != MIPT_OK || cnt == 0 || cnt > (uint32_t)(2 * n - 1 + (n == 1))) return 4;
     }
-    printf("sanitize_host ok: loader %d ok / %d rejected, png %d decoded / %d rejected, jpeg %d decoded / %d rejected\n", ok, bad, decoded, rejected,
+    printf("sanitize_host ok: loader %d ok / %d rejected, png %d decoded / %d rejected, jpeg+tga+bmp %d decoded / %d rejected\n", ok, bad, decoded, rejected,
            jdecoded, jrejected);
     return 0;
 }

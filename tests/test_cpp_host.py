@@ -36,7 +36,7 @@ def test_cpp_host_mirror_renders_config1(built, tmp_path):
 
 
 def test_host_code_under_asan_ubsan(built, tmp_path):
-    """GPU sanitizers are unavailable: the host-side C++ that parses untrusted files (OBJ/MTL, PNG, JPEG) and the BVH builder
+    """GPU sanitizers are unavailable: the host-side C++ that parses untrusted files (OBJ/MTL, PNG, JPEG, TGA, BMP) and the BVH builder
     run under AddressSanitizer + UBSan on the CPU, with truncated / bit-flipped inputs."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,7 +54,7 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
                            os.path.join(src, "bvh_build.cpp"), os.path.join(src, "obj_loader.cpp"), os.path.join(src, "png_decode.cpp"),
-                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe, "-lpthread"])
+                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(src, "tga_bmp_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe, "-lpthread"])
     jpegs = []
     try:
         from PIL import Image
@@ -66,6 +66,13 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
             except (TypeError, ValueError):
                 continue
             jpegs.append(p)
+        rgba = np.random.default_rng(3).integers(0, 256, (19, 23, 4), dtype=np.uint8)
+        rgba[:, :9] = rgba[:1, :1]
+        for name, kw in (("a.tga", dict(compression="tga_rle")), ("b.tga", dict()), ("c.bmp", dict())):
+            Image.fromarray(rgba, "RGBA").save(str(tmp_path / name), **kw)
+            jpegs.append(str(tmp_path / name))
+        Image.fromarray(rgba[..., :3], "RGB").convert("P").save(str(tmp_path / "d.bmp"))
+        jpegs.append(str(tmp_path / "d.bmp"))
     except ImportError:
         pass
     out = subprocess.run([exe, str(tmp_path), str(tmp_path / "tex.png")] + jpegs, capture_output=True, text=True,

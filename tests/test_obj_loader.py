@@ -350,3 +350,87 @@ def test_png_every_colour_type_and_depth(rrt, tmp_path, interlace):
                     assert np.array_equal(got, np.asarray(Image.open(p).convert("RGBA"))), (h, w, ctype, depth, interlace)
                 elif depth < 8:
                     assert np.array_equal(got[..., :3], np.asarray(Image.open(p).convert("RGB"))), (h, w, ctype, depth, interlace)
+
+
+def test_png_decoder_on_the_reference_gallery_images(rrt):
+    """The reference ships four 1920-wide gallery PNGs (README.md) -- real encoder output (adaptive filters, big deflate
+    streams) rather than this file's own writer.  Read in place as data (skipped where /root/reference is absent), decoded
+    by Texture::load's path and compared with Pillow's decoder."""
+    Image = pytest.importorskip("PIL.Image")
+    import glob
+    files = sorted(glob.glob("/root/reference/*.png"))
+    if not files:
+        pytest.skip("/root/reference is not present on this machine")
+    for f in files:
+        t = rrt.Texture.load(f)
+        assert t is not None, f
+        want = np.asarray(Image.open(f).convert("RGBA"))[::-1]
+        assert (t.height, t.width) == want.shape[:2] and np.array_equal(t.pixel_data, want), f
+
+
+# ---- TGA / BMP textures (tga_bmp_decode.cpp) -------------------------------------------------------------------------
+def test_tga_and_bmp_decoders_match_pillow(rrt, tmp_path):
+    """Texture::load on the two other lossless formats OBJ exports carry: every variant Pillow can write (TGA grey / grey+alpha /
+    RGB / RGBA / colour-mapped, raw and run-length, both vertical origins; BMP 1 / 8 / 24 / 32 bit incl. BITFIELDS with alpha)
+    plus hand-built files it cannot (16-bit 5-5-5 TGA and BMP, 4-bit and top-down BMP, the 12-byte CORE header), all compared
+    with Pillow's readers."""
+    Image = pytest.importorskip("PIL.Image")
+    import struct
+    rng = np.random.default_rng(5)
+
+    def check(p, want=None):
+        t = rrt.Texture.load(p)
+        assert t is not None, p
+        if want is None:
+            want = np.asarray(Image.open(p).convert("RGBA"))[::-1]
+        assert t.pixel_data.shape == want.shape and np.array_equal(t.pixel_data, want), p
+
+    def want555(v16, flip):                                 # 5-bit fields rounded to 8 bits (Pillow truncates instead)
+        c = np.stack([(v16 >> 10) & 31, (v16 >> 5) & 31, v16 & 31], -1).astype(np.uint32)
+        out = np.concatenate([((c * 255 + 15) // 31).astype(np.uint8), np.full(v16.shape + (1,), 255, np.uint8)], -1)
+        return out if flip else out[::-1]
+
+    n = 0
+    for (h, w) in [(13, 21), (1, 1), (7, 5), (32, 33)]:
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        rgba[:, : w // 2] = rgba[:1, :1]                    # runs, so the run-length files hold both packet kinds
+        for mode, arr in [("RGBA", rgba), ("RGB", rgba[..., :3]), ("L", rgba[..., 0]), ("LA", rgba[..., :2])]:
+            im = Image.fromarray(arr, mode)
+            for rle in (False, True):
+                for orient in (1, -1):
+                    p = str(tmp_path / f"t{n}.tga"); n += 1
+                    im.save(p, compression="tga_rle" if rle else None, orientation=orient)
+                    check(p)
+            if mode != "LA":
+                p = str(tmp_path / f"b{n}.bmp"); n += 1
+                im.save(p); check(p)
+        pim = Image.fromarray(rgba[..., :3], "RGB").convert("P", palette=Image.ADAPTIVE, colors=17)
+        for ext, kw in (("tga", dict()), ("tga", dict(compression="tga_rle")), ("bmp", dict())):
+            p = str(tmp_path / f"p{n}.{ext}"); n += 1
+            pim.save(p, **kw); check(p)
+        p = str(tmp_path / f"one{n}.bmp"); n += 1
+        Image.fromarray((rgba[..., 0] > 127).astype(np.uint8) * 255, "L").convert("1").save(p); check(p)
+        # hand-built: 16-bit TGA, bottom-up
+        v16 = rng.integers(0, 1 << 15, (h, w)).astype("<u2")
+        p = str(tmp_path / f"h{n}.tga"); n += 1
+        open(p, "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, w, h, 16, 0) + v16.tobytes()); check(p, want555(v16, True))
+        # hand-built BMPs: 16-bit BI_RGB, 4-bit palette, top-down 24-bit, CORE-header 24-bit
+        def bmp(bits, rows_bytes, height_field, palette=b"", core=False):
+            hdr = struct.pack("<IHHHH", 12, w, h, 1, bits) if core else struct.pack("<IiiHHIIiiII", 40, w, height_field, 1, bits, 0, 0, 2835, 2835, len(palette) // 4, 0)
+            off = 14 + len(hdr) + len(palette)
+            body = b"".join(r + b"\0" * ((-len(r)) % 4) for r in rows_bytes)
+            return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + hdr + palette + body
+        p = str(tmp_path / f"h{n}.bmp"); n += 1
+        open(p, "wb").write(bmp(16, [v16[y].tobytes() for y in range(h)], h)); check(p, want555(v16, True))
+        idx = rng.integers(0, 16, (h, w)).astype(np.uint8)
+        packed = [bytes((int(r[i]) << 4) | (int(r[i + 1]) if i + 1 < w else 0) for i in range(0, w, 2)) for r in idx]
+        p = str(tmp_path / f"h{n}.bmp"); n += 1
+        open(p, "wb").write(bmp(4, packed, h, palette=rng.integers(0, 256, 64, dtype=np.uint8).tobytes())); check(p)
+        p = str(tmp_path / f"h{n}.bmp"); n += 1
+        open(p, "wb").write(bmp(24, [rgba[y, :, 2::-1].tobytes() for y in range(h)], -h)); check(p)
+        p = str(tmp_path / f"h{n}.bmp"); n += 1
+        open(p, "wb").write(bmp(24, [rgba[y, :, 2::-1].tobytes() for y in range(h)], h, core=True)); check(p)
+    # rejected cleanly
+    (tmp_path / "bad.tga").write_bytes(b"\0" * 10)
+    (tmp_path / "bad.bmp").write_bytes(b"BM" + b"\0" * 40)
+    assert rrt.Texture.load(str(tmp_path / "bad.tga")) is None and rrt.Texture.load(str(tmp_path / "bad.bmp")) is None
