@@ -335,7 +335,7 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
 #endif
 template <bool COUNT, bool CULL, bool LDS_TOP, int SHADING>
 __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_trace_kernel(DevScene sc, DevParams pr) {
-    __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds][64];
+    __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];   // row kStackLds: scratch target of the branch-free push
     __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
     if (LDS_TOP) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)kTopPairs * 4u; i += kBlockThreads) s_top[i] = sc.top[i];
@@ -534,6 +534,8 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
             const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * 48u) : (pair * 64u);
             unsigned long long g_ta = 0;
             if (COUNT && DIAG_STAMPS) g_ta = clock64();
+            // top of the stack, read now so that its LDS latency hides under the global loads: a step that pops never pushes
+            const uint32_t top_e = stk[(sp - 1u) & (uint32_t)(kStackLds - 1)][lane];
             float4 r0, r1, r2, r3;
             if (LDS_TOP && !leaf && (pair & kTopFlag)) {                 // tree top: 64 B from LDS
                 const float4 *q = s_top + (pair & 0xffffu) * 4u;
@@ -587,19 +589,16 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                 if (d1 == kMiss) {                                                   // ray.rs:124-130
                     need_pop = true;
                 } else {
-                    if (d2 < kMiss) {                                                // ray.rs:133-136
-                        const uint32_t e = encode_child(a2, n2, pair, w2);
-                        if (sp < (uint32_t)kStackLds) {
-                            stk[sp][lane] = e;
-                            sp += 1;
-                        } else if (sp < (uint32_t)(kStackLds + kStackOvf)) {
-                            ovf[(size_t)(sp - kStackLds) * 64] = e;
-                            sp += 1;
-                        } else {
-                            atomicAdd(&pr.stats->stack_overflows, 1ull);             // reference: panic (ray.rs:85)
-                        }
-                        if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
+                    const bool push = d2 < kMiss;                                    // ray.rs:133-136
+                    const uint32_t e = encode_child(a2, n2, pair, w2);
+                    const bool in_lds = sp < (uint32_t)kStackLds;
+                    stk[(push && in_lds) ? sp : (uint32_t)kStackLds][lane] = e;      // no branch: non-pushing lanes hit the scratch row
+                    if (push && !in_lds) {                                           // rare: spill region / overflow
+                        if (sp < (uint32_t)(kStackLds + kStackOvf)) ovf[(size_t)(sp - kStackLds) * 64] = e;
+                        else atomicAdd(&pr.stats->stack_overflows, 1ull);             // reference: panic (ray.rs:85)
                     }
+                    sp += (push && sp < (uint32_t)(kStackLds + kStackOvf)) ? 1u : 0u;
+                    if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                     if (n1 > 0u) { tri_cur = a1; tri_end = a1 + n1; }                // ray.rs:131 node = child_1
                     else { pair = a1; }
                 }
@@ -609,7 +608,8 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                     state = ST_S;
                 } else {
                     sp -= 1;
-                    const uint32_t e = (sp < (uint32_t)kStackLds) ? stk[sp][lane] : ovf[(size_t)(sp - kStackLds) * 64];
+                    uint32_t e = top_e;
+                    if (sp >= (uint32_t)kStackLds) e = ovf[(size_t)(sp - kStackLds) * 64];  // rare
                     if (e & 0x80000000u) {
                         uint32_t n = (e >> 25) & 63u, a = e & 0x01ffffffu;
                         if (n == 0u) {                                               // big leaf: child-ref form
