@@ -1,6 +1,6 @@
 """GPU box: config M with the wgpu shader's material model (shading mode 1) -- measurement row for DESIGN.md."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rust_ray_tracing_amd as rrt
 from rust_ray_tracing_amd import synth, _lib as L

@@ -1,6 +1,6 @@
 """GPU box: full-size frame, GPU culled / GPU reference / oracle culled / oracle reference on a strided sample."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rust_ray_tracing_amd as rrt
 from rust_ray_tracing_amd import synth

@@ -1,6 +1,6 @@
 """Debug helper (GPU box): render one case with the HIP path and the oracle, report where they differ."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rust_ray_tracing_amd as rrt
 from rust_ray_tracing_amd import synth

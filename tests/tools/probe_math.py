@@ -1,6 +1,6 @@
 """GPU box: compare device arithmetic primitives with the oracle / numpy bit for bit."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rust_ray_tracing_amd as rrt
 from oracle import orc
