@@ -212,6 +212,11 @@ typedef struct MiptImage MiptImage;
 int  mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out);
 void mipt_texture_free(MiptImage *img);
 
+/* The image output of Renderer::render (src/renderer.rs:66-83, image::save_buffer): writes width x height RGBA pixels,
+ * top row first, as a PNG with 8 or 16 bits per sample (16-bit samples in host byte order; the reference saves
+ * ColorType::Rgba16, and the bytes of its CPU arm are RGBA8 -- SURVEY T12).  Uncompressed deflate blocks. */
+int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba);
+
 /* The same build on the GPU (level-synchronous binned SAH with the partition's closed-form permutation); identical output
  * (sign of zero in a bound aside).  Uploads `tris`, downloads the reordered triangles and the nodes; build_ms_out (may be
  * NULL) receives the device time of the build itself without the transfers. */

@@ -129,6 +129,12 @@ class Renderer {                                           // src/renderer.rs:8-
         const int rc = mipt_render(h, &scene.camera.uniform, &o, nullptr, out.data(), nullptr);
         mipt_scene_destroy(h);
         if (rc != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        if (options.output_image_path) {                                   // renderer.rs:66-83 (as Rgba8: SURVEY T12)
+            if (mipt_image_save_png(options.output_image_path->c_str(), o.width, o.height, 8, out.data()) == MIPT_OK)
+                std::fprintf(stderr, "[INFO] Succesfully wrote image data to '%s'\n", options.output_image_path->c_str());
+            else
+                log_error(mipt_last_error());
+        }
         return out;
     }
 };

@@ -73,7 +73,7 @@ EXPORTS = [
     "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_postprocess_device", "mipt_bvh_build", "mipt_bvh_build_device",
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
     "mipt_device_count", "mipt_debug_eval", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
-    "mipt_texture_load", "mipt_texture_free",
+    "mipt_texture_load", "mipt_texture_free", "mipt_image_save_png",
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def load() -> C.CDLL:
     lib.mipt_texture_load.restype = C.c_int
     lib.mipt_texture_free.argtypes = [vp]
     lib.mipt_texture_free.restype = None
+    lib.mipt_image_save_png.argtypes = [C.c_char_p, u32, u32, u32, vp]
+    lib.mipt_image_save_png.restype = C.c_int
     _lib = lib
     return lib
 

@@ -25,7 +25,10 @@
 #include <vector>
 
 void mipt_internal_set_error(const char *msg);   // mipt_api.cpp: feeds mipt_last_error()
-namespace mipt_png { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
+namespace mipt_png {
+bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err);
+bool write_rgba(const std::string &path, uint32_t w, uint32_t h, int bits, const void *rgba, std::string *err);
+}
 namespace mipt_jpeg { bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err); }
 namespace mipt_img {
 bool decode_tga(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err);
@@ -439,5 +442,12 @@ int mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, 
     return MIPT_OK;
 }
 void mipt_texture_free(MiptImage *img) { delete img; }
+
+int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba) {
+    if (!path || !rgba) return fail("mipt_image_save_png: null argument");
+    std::string err;
+    if (!mipt_png::write_rgba(path, width, height, (int)bits_per_sample, rgba, &err)) return fail("Failed to write image data: " + err);   // renderer.rs:79-82
+    return MIPT_OK;
+}
 
 } // extern "C"

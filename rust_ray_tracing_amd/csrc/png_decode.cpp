@@ -248,4 +248,69 @@ bool decode(const std::string &path, uint32_t *w_out, uint32_t *h_out, std::vect
     return true;
 }
 
+
+// ---- writer: the image output of Renderer::render (reference src/renderer.rs:66-83, image::save_buffer) ---------------
+// RGBA, 8 or 16 bits per sample (16-bit samples are taken in host order and stored big-endian), filter type 0, zlib
+// "stored" blocks -- a valid PNG without a compressor; rows top first.
+bool write_rgba(const std::string &path, uint32_t w, uint32_t h, int bits, const void *rgba, std::string *err) {
+    if (w == 0 || h == 0 || (bits != 8 && bits != 16) || !rgba) { *err = "bad PNG write arguments"; return false; }
+    static uint32_t crc_table[256];
+    static bool have_table = false;
+    if (!have_table) {
+        for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; }
+        have_table = true;
+    }
+    auto crc = [&](uint32_t c, const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 255u] ^ (c >> 8); return c; };
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { *err = "cannot create '" + path + "'"; return false; }
+    auto put32 = [](uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+    auto chunk = [&](const char *tag, const std::vector<uint8_t> &data) {
+        uint8_t hd[8];
+        put32(hd, (uint32_t)data.size()); memcpy(hd + 4, tag, 4);
+        uint32_t c = crc(0xffffffffu, hd + 4, 4);
+        c = crc(c, data.data(), data.size()) ^ 0xffffffffu;
+        uint8_t tail[4];
+        put32(tail, c);
+        return fwrite(hd, 1, 8, f) == 8 && (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) && fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    bool ok = fwrite(sig, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr(13);
+    put32(&ihdr[0], w); put32(&ihdr[4], h); ihdr[8] = (uint8_t)bits; ihdr[9] = 6; ihdr[10] = ihdr[11] = ihdr[12] = 0;
+    ok = ok && chunk("IHDR", ihdr);
+    // raw scanlines (filter byte 0 + samples), then a zlib stream of stored blocks
+    const size_t row = (size_t)w * 4 * (size_t)(bits / 8), total = (row + 1) * h;
+    std::vector<uint8_t> raw(total);
+    for (uint32_t y = 0; y < h; y++) {
+        uint8_t *d = &raw[(row + 1) * y];
+        d[0] = 0;
+        if (bits == 8) {
+            memcpy(d + 1, (const uint8_t *)rgba + row * y, row);
+        } else {
+            const uint16_t *s = (const uint16_t *)rgba + (size_t)w * 4 * y;
+            for (size_t i = 0; i < (size_t)w * 4; i++) { d[1 + 2 * i] = (uint8_t)(s[i] >> 8); d[2 + 2 * i] = (uint8_t)s[i]; }
+        }
+    }
+    std::vector<uint8_t> z;
+    z.reserve(total + total / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < total || pos == 0; ) {
+        const size_t n = total - pos < 65535 ? total - pos : 65535;
+        z.push_back(pos + n >= total ? 1 : 0);
+        z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        for (size_t i = 0; i < n; i++) { a += raw[pos + i]; if (a >= 65521u) a -= 65521u; b += a; if (b >= 65521u) b -= 65521u; }
+        pos += n;
+        if (n == 0) break;
+    }
+    uint8_t ad[4];
+    put32(ad, b << 16 | a);
+    z.insert(z.end(), ad, ad + 4);
+    ok = ok && chunk("IDAT", z) && chunk("IEND", {});
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) *err = "short write to '" + path + "'";
+    return ok;
+}
+
 } // namespace mipt_png

@@ -13,7 +13,7 @@ int main(int argc, char **argv) {
     const std::string mode = argv[1], obj = argv[2];
     // Renderer::new validation (renderer.rs:15-34)
     RendererOptions o;
-    o.is_realtime = false; o.backend = RendererBackend::MI355X; o.output_image_path = "out.png";
+    o.is_realtime = false; o.backend = RendererBackend::MI355X; o.output_image_path = argc >= 5 ? argv[4] : "/tmp/mipt_test_host_out.png";
     { auto b = o; b.output_image_dimensions = {0, 5}; CHECK(!Renderer::create(b)); }
     { auto b = o; b.max_ray_depth = 0; CHECK(!Renderer::create(b)); }
     { auto b = o; b.samples = 0; CHECK(!Renderer::create(b)); }
@@ -29,6 +29,24 @@ int main(int argc, char **argv) {
     cam.position[0] = 3.2f;
     scene->set_camera(cam);
     CHECK(scene->camera.uniform.look_at[2][0] == -1.0f && scene->camera.uniform.position.x == 3.2f);   // looks down -X
+    {   // image output (renderer.rs:66-83) through the ABI: 8- and 16-bit RGBA, read back by Texture::load
+        const uint32_t w = 5, h = 3;
+        std::vector<uint8_t> p8(w * h * 4);
+        std::vector<uint16_t> p16(w * h * 4);
+        for (size_t i = 0; i < p8.size(); i++) { p8[i] = (uint8_t)(i * 37 + 11); p16[i] = (uint16_t)(i * 2654435761u >> 7); }
+        const std::string base = obj.substr(0, obj.find_last_of('/'));
+        CHECK(mipt_image_save_png((base + "/w8.png").c_str(), w, h, 8, p8.data()) == MIPT_OK);
+        CHECK(mipt_image_save_png((base + "/w16.png").c_str(), w, h, 16, p16.data()) == MIPT_OK);
+        CHECK(mipt_image_save_png("/nonexistent-dir/x.png", w, h, 8, p8.data()) != MIPT_OK);
+        CHECK(mipt_image_save_png((base + "/bad.png").c_str(), w, h, 12, p8.data()) != MIPT_OK);
+        auto t8 = Texture::load(base + "/w8.png");
+        CHECK(t8 && t8->width == w && t8->height == h);
+        for (uint32_t y = 0; y < h; y++) CHECK(memcmp(&t8->pixel_data[(size_t)(h - 1 - y) * w * 4], &p8[(size_t)y * w * 4], w * 4) == 0);   // flipv
+        auto t16 = Texture::load(base + "/w16.png");
+        CHECK(t16 && t16->width == w);
+        for (uint32_t y = 0; y < h; y++) for (uint32_t i = 0; i < w * 4; i++)
+            CHECK(t16->pixel_data[(size_t)(h - 1 - y) * w * 4 + i] == (uint8_t)((p16[(size_t)y * w * 4 + i] + 128u) / 257u));
+    }
     if (mode == "cpu") { printf("host mirror (cpu) ok\n"); return 0; }
     CHECK(argc >= 4);
     o.samples = 4; o.max_ray_depth = 64; o.output_image_dimensions = {256, 256};
