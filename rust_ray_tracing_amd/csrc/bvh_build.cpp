@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -217,8 +218,8 @@ void place(const Sub &sub, MiptNode *nodes, uint32_t off, MiptNode &self) {
 
 } // namespace
 
-extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
-                              uint32_t *n_nodes_out, uint32_t threads) {
+static int bvh_build_impl(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
+                          uint32_t *n_nodes_out, uint32_t threads) {
     if (!tris || !nodes_out || n_tris == 0 || nodes_cap == 0) return MIPT_ERR_INVALID_ARG;   // empty scene: the reference panics
     std::vector<Proxy> px(n_tris);
     Box root; root.reset();
@@ -253,4 +254,14 @@ extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nod
     std::vector<MiptTriangle> tmp(tris, tris + n_tris);
     for (uint32_t i = 0; i < n_tris; i++) tris[i] = tmp[px[i].idx];
     return MIPT_OK;
+}
+
+// No C++ exception may cross the C ABI (allocation or thread-creation failure on the calling thread -> status code).
+extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
+                              uint32_t *n_nodes_out, uint32_t threads) {
+    try {
+        return bvh_build_impl(tris, n_tris, nodes_out, nodes_cap, n_nodes_out, threads);
+    } catch (const std::exception &) {
+        return MIPT_ERR_INVALID_ARG;
+    }
 }

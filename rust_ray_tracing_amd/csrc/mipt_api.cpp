@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -121,7 +122,7 @@ void mipt_material_default(MiptMaterial *m) {        // scene.rs:148-167
         m->emission_tex_id = m->normal_tex_id = UINT32_MAX;
 }
 
-int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
+static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
     if (!desc || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
     *out = nullptr;
     if (!desc->tris || desc->n_tris == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no triangles (the reference panics in BVH::build)");
@@ -317,6 +318,13 @@ int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out)
     *out = s;
     return MIPT_OK;
 }
+
+// No C++ exception may cross the C ABI (the caller may be Rust or C): allocation failures become status codes.
+#define MIPT_NO_THROW(call)                                                                                             \
+    try { return call; }                                                                                               \
+    catch (const std::bad_alloc &) { return fail(MIPT_ERR_INVALID_ARG, "out of host memory"); }                        \
+    catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, "internal error: %s", e.what()); }
+int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out) { MIPT_NO_THROW(scene_create_impl(desc, device_id, out)) }
 
 void mipt_scene_destroy(MiptScene *scene) { free_scene(scene); }
 

@@ -21,6 +21,8 @@
 #include <fstream>
 #include <memory>
 #include <sstream>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -305,7 +307,7 @@ bool tris_from_face(const std::string &s, std::vector<ObjTri> *out) { // obj.rs:
 
 extern "C" {
 
-int mipt_obj_load(const char *path_c, MiptObj **out) {
+static int obj_load_impl(const char *path_c, MiptObj **out) {
     if (!path_c || !out) return fail("mipt_obj_load: null argument");
     *out = nullptr;
     const std::string path = path_c;
@@ -427,7 +429,7 @@ void mipt_obj_free(MiptObj *obj) { delete obj; }
 
 struct MiptImage { Tex t; };
 
-int mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out) {
+static int texture_load_impl(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out) {
     if (!path || !out || !desc_out) return fail("mipt_texture_load: null argument");
     *out = nullptr;
     FILE *f = fopen(path, "rb");
@@ -443,11 +445,23 @@ int mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, 
 }
 void mipt_texture_free(MiptImage *img) { delete img; }
 
-int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba) {
+static int image_save_png_impl(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba) {
     if (!path || !rgba) return fail("mipt_image_save_png: null argument");
     std::string err;
     if (!mipt_png::write_rgba(path, width, height, (int)bits_per_sample, rgba, &err)) return fail("Failed to write image data: " + err);   // renderer.rs:79-82
     return MIPT_OK;
+}
+
+
+// No C++ exception may cross the C ABI: allocation failures and parser surprises become status codes.
+#define MIPT_NO_THROW(call)                                                                \
+    try { return call; }                                                                  \
+    catch (const std::bad_alloc &) { return fail("out of host memory"); }                 \
+    catch (const std::exception &e) { return fail(std::string("internal error: ") + e.what()); }
+int mipt_obj_load(const char *path, MiptObj **out) { MIPT_NO_THROW(obj_load_impl(path, out)) }
+int mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out) { MIPT_NO_THROW(texture_load_impl(path, out, desc_out, hash_out)) }
+int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba) {
+    MIPT_NO_THROW(image_save_png_impl(path, width, height, bits_per_sample, rgba))
 }
 
 } // extern "C"
