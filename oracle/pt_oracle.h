@@ -10,8 +10,10 @@
  * PARITY STATUS: "parity unpinned" by the reference -- the reference ships no
  * tests, golden vectors or fixtures and cannot be compiled here
  * (Rust toolchain absent).  The oracle is pinned instead by the
- * hand-derived known answers of SURVEY.md Appendix B (tests/test_oracle_kat.py)
- * and by goldens it emitted itself (tests/golden/).
+ * hand-derived known answers of SURVEY.md Appendix B (tests/test_oracle_kat.py),
+ * by goldens it emitted itself (tests/golden/), and by a second restatement written
+ * from the Rust sources independently (pt_oracle_py.py) that must agree with it bit
+ * for bit (tests/test_oracle_second_reading.py).
  *
  * Every function cites the reference file:line it follows.
  */

@@ -1,0 +1,77 @@
+"""CPU: the C oracle against a second, independent restatement of the reference (oracle/pt_oracle_py.py, pure Python over
+float32 scalars, written from the Rust sources a second time).  The reference has no tests or fixtures and cannot be built
+here, so two readings that agree bit for bit are the strongest pin available for "did the oracle misread the Rust?"."""
+import numpy as np
+import pytest
+
+
+def _scene(rrt, kind, **kw):
+    from rust_ray_tracing_amd import synth
+    tris, mats, texs, cam = synth.make_scene(kind, **kw)
+    sc = rrt.Scene.from_arrays(tris, mats, texs)
+    sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    return sc
+
+
+@pytest.mark.parametrize("kind,kw,w,h,spp,depth,stride", [
+    ("cornell", {}, 24, 24, 3, 8, 1),                                   # closed box: every path runs to max depth or the light
+    ("atrium", dict(n_target=2500, tex_size=16), 48, 27, 2, 12, 7),     # textured materials (base colour + emission maps), sky escapes
+    ("dragon", dict(n_target=1500), 40, 30, 2, 6, 5),                   # thin spiky geometry: grazing hits, back faces
+])
+def test_radiance_and_counters_agree_bit_for_bit(rrt, orc, kind, kw, w, h, spp, depth, stride):
+    from oracle import pt_oracle_py as py
+    sc = _scene(rrt, kind, **kw)
+    pixels = list(range(0, w * h, stride))
+    got, cnt = py.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, w, h, spp, depth, pixels=pixels)
+    ref, _, st = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, w, h, spp, depth,
+                            pix_begin=0, pix_stride=stride, want_rgba8=False)
+    ref = ref.reshape(-1, 3)
+    for p in pixels:
+        a = np.array(got[p], dtype=np.float32)
+        assert np.array_equal(a.view(np.uint32), ref[p].view(np.uint32)), (kind, p, a, ref[p])
+    for k in ("rays", "inner_steps", "tri_tests"):
+        assert cnt[k] == st[k], k
+    assert cnt["rays"] > len(pixels) * spp                                 # bounces happened
+
+
+def test_transcendental_shim_restated_in_python_matches_c(orc):
+    from oracle import pt_oracle_py as py
+    import ctypes as C
+    lib = orc.load()
+    lib.orc_shim_cosf.restype = C.c_float; lib.orc_shim_cosf.argtypes = [C.c_float]
+    lib.orc_shim_log10f.restype = C.c_float; lib.orc_shim_log10f.argtypes = [C.c_float]
+    rng = np.random.default_rng(4)
+    xs = np.concatenate([rng.uniform(0, 6.2832, 3000), rng.uniform(-50, 50, 500), [0.0, 1.5707964, 3.1415927, 6.283185]]).astype(np.float32)
+    for x in xs:
+        assert np.float32(lib.orc_shim_cosf(float(x))).view(np.uint32) == py.shim_cosf(x).view(np.uint32), x
+    us = np.concatenate([rng.uniform(0, 1, 3000), rng.uniform(0, 1e-6, 200), [1.0, 0.5, 2.3283064e-10]]).astype(np.float32)
+    for u in us:
+        assert np.float32(lib.orc_shim_log10f(float(u))).view(np.uint32) == py.shim_log10f(u).view(np.uint32), u
+    seeds = rng.integers(1, 2**32, 300)
+    lib.orc_rand_in_unit_sphere.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float * 3)]
+    for s in seeds:
+        st = C.c_uint32(int(s)); out = (C.c_float * 3)()
+        lib.orc_rand_in_unit_sphere(C.byref(st), orc.LIBM_SHIM, C.byref(out))
+        ps = [int(s)]
+        v = py.rand_in_unit_sphere(ps)
+        assert ps[0] == st.value
+        assert np.array_equal(np.array(v, np.float32).view(np.uint32), np.array(list(out), np.float32).view(np.uint32)), s
+
+
+@pytest.mark.parametrize("kind,kw", [("cornell", {}), ("helmet", dict(n_target=300, tex_size=8)), ("dragon", dict(n_target=400))])
+def test_bvh_builder_second_reading(rrt, orc, kind, kw):
+    """BVH::build read a second time (pure Python) against the C oracle's pass-for-pass builder: same node array (sign of
+    zero aside, as everywhere) and the same triangle order."""
+    from oracle import pt_oracle_py as py
+    from rust_ray_tracing_amd import synth
+    tris, _, _, _ = synth.make_scene(kind, **kw)
+    t_py, n_py = py.build_bvh(tris)
+    from rust_ray_tracing_amd import _lib as L
+    t_c, n_c = orc.bvh_build(tris)
+    n_c = np.ascontiguousarray(n_c).view(np.uint8).reshape(-1).view(L.NODE)
+    assert np.array_equal(t_py.view(np.uint8), np.ascontiguousarray(t_c).view(np.uint8))
+    assert len(n_py) == len(n_c)
+    for a, b in zip(n_py, n_c):
+        assert a["first_tri_or_child"] == int(b["first_tri_or_child"]) and a["num_tris"] == int(b["num_tris"])
+        assert np.array_equal(np.array(a["bounds_min"], np.float32) + 0.0, np.asarray(b["bounds_min"]) + 0.0)
+        assert np.array_equal(np.array(a["bounds_max"], np.float32) + 0.0, np.asarray(b["bounds_max"]) + 0.0)
