@@ -1,6 +1,6 @@
 """GPU box: kernel time of ONE rank's tile share (world = 2, 4, 8) with lane regrouping off / on, vs blocks per CU and park threshold."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rust_ray_tracing_amd as rrt
 from rust_ray_tracing_amd import synth, _lib as L
@@ -15,7 +15,7 @@ buf = np.zeros(w * h * 3, dtype=np.float32)
 
 
 def run(world, env):
-    for k in ("MIPT_REGROUP", "MIPT_PARK_LANES", "MIPT_BLOCKS_PER_CU"):
+    for k in ("MIPT_REGROUP", "MIPT_PARK_LANES", "MIPT_BLOCKS_PER_CU", "MIPT_REGROUP_FRAC"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ts = []
@@ -30,10 +30,11 @@ def run(world, env):
 for world in (8, 4, 2, 1):
     base, ref = run(world, {"MIPT_REGROUP": "0"})
     print("world", world, "off(auto bpc)", base, flush=True)
-    for bpc in ("2", "3", "4"):
-        for pl in ("16", "32", "48"):
-            t, out = run(world, {"MIPT_REGROUP": "1", "MIPT_PARK_LANES": pl, "MIPT_BLOCKS_PER_CU": bpc})
-            same = bool(np.array_equal(out.view(np.uint32), ref.view(np.uint32)))
-            print("world", world, "regroup bpc", bpc, "park_lanes", pl, t, "identical" if same else "DIFFERENT", flush=True)
+    for bpc in ("3", "5"):
+        for pl in ("32",):
+            for fr in ("0.25", "0.5", "0.75"):
+                t, out = run(world, {"MIPT_REGROUP": "1", "MIPT_PARK_LANES": pl, "MIPT_BLOCKS_PER_CU": bpc, "MIPT_REGROUP_FRAC": fr})
+                same = bool(np.array_equal(out.view(np.uint32), ref.view(np.uint32)))
+                print("world", world, "regroup bpc", bpc, "park_lanes", pl, "frac", fr, t, "identical" if same else "DIFFERENT", flush=True)
     t, out = run(world, {})
     print("world", world, "auto", t, "identical" if np.array_equal(out.view(np.uint32), ref.view(np.uint32)) else "DIFFERENT", flush=True)
