@@ -1,4 +1,4 @@
-"""Second, independent CPU restatement of the reference's rayon path tracer and BVH builder -- TEST INFRASTRUCTURE ONLY.
+"""Second, independent CPU restatement of the reference's rayon path tracer, BVH builder and OBJ/MTL flatten -- TEST INFRASTRUCTURE ONLY.
 
 Written from the Rust sources again, in pure Python over numpy float32 scalars (one rounded IEEE operation per Rust
 operator), for SMALL cases only (a few hundred pixels): tests/test_oracle_second_reading.py requires it to agree bit for bit
@@ -8,7 +8,7 @@ fixtures); cos / log10 / powf go through the same deterministic binary64 shim sp
 
 Reference lines followed: src/renderer/backend/cpu.rs:13-68, src/renderer/backend/cpu/ray.rs:19-227, src/math.rs:6-24,
 src/math/vec3.rs:66-109,130-205,252-366, src/math/mat4.rs:143-152, src/texture.rs:33-38, src/bvh.rs:13-203,
-src/scene.rs:114-126.
+src/scene.rs:44-85,114-167, src/loader/obj.rs:16-436 (geometry and scalar material keys; texture maps are not followed).
 """
 import math
 import struct
@@ -363,3 +363,143 @@ def build_bvh(tris):
     with np.errstate(all="ignore"):
         split(0)
     return tris, [dict(bounds_min=tuple(n.lo), first_tri_or_child=n.first, bounds_max=tuple(n.hi), num_tris=n.n) for n in nodes]
+
+
+# ---- loader/obj.rs + scene.rs:44-85 (second reading of the host flatten for config 1) ---------------------------------
+def _parse_f32(s):
+    """str::parse::<f32>: the decimal value correctly rounded to binary32 (no double rounding through binary64)."""
+    from fractions import Fraction
+    d = float(s)                                            # raises ValueError like parse().unwrap() panics
+    f = np.float32(d)
+    if not np.isfinite(f) or "n" in s.lower() or "i" in s.lower():
+        return f
+    try:
+        exact = Fraction(s)
+    except ValueError:
+        return f
+    best = f
+    for cand in (np.nextafter(f, np.float32(-np.inf)), np.nextafter(f, np.float32(np.inf))):
+        if not np.isfinite(cand):
+            continue
+        db, dc = abs(Fraction(float(best)) - exact), abs(Fraction(float(cand)) - exact)
+        if dc < db or (dc == db and (int(np.float32(cand).view(np.uint32)) & 1) == 0):
+            best = np.float32(cand)
+    return best
+
+
+def material_default():                                     # scene.rs:148-167
+    return dict(base_color=[F(0.8)] * 3, transmission=F(0), specular_tint=[F(1)] * 3, ior=F(1.45), emission=[F(0)] * 3,
+                roughness=F(1), metallic=F(0), transparency=F(1), base_color_tex_id=U32, transparency_tex_id=U32,
+                roughness_tex_id=U32, metallic_tex_id=U32, emission_tex_id=U32, normal_tex_id=U32)
+
+
+def load_mtl(path):                                         # obj.rs:131-265 (texture maps are not followed here)
+    mats = {}                                               # insertion-ordered stand-in for the HashMap (its order is random)
+    lines = iter(open(path).read().splitlines())
+    for line in lines:
+        if not line.startswith("newmtl "):
+            continue
+        name, m = line[len("newmtl "):], material_default()
+        for line2 in lines:
+            tok = line2.split()
+            if not tok:
+                break
+            p, a = tok[0], tok[1:]
+            if p in ("Kd", "Ks", "Ke"):
+                key = {"Kd": "base_color", "Ks": "specular_tint", "Ke": "emission"}[p]
+                m[key] = list(m[key])
+                for i, v in enumerate(a):
+                    m[key][i] = _parse_f32(v)               # a 4th value would panic (index out of bounds)
+            elif p in ("Ni", "Pr", "Pm", "Tf", "d"):
+                m[{"Ni": "ior", "Pr": "roughness", "Pm": "metallic", "Tf": "transmission", "d": "transparency"}[p]] = _parse_f32(a[0])
+        mats[name] = m
+    return mats
+
+
+def load_obj(path):
+    """OBJ::load + Scene::from(OBJ) up to (not including) BVH::build: returns (fat triangles as a TRIANGLE-dtype array,
+    [(name, material dict)] in id order)."""
+    import os
+    from rust_ray_tracing_amd import _lib as L
+    lines = open(path).read().splitlines()
+    mtl_line = next((ln for ln in lines if ln.lstrip().startswith("mtllib")), None)
+    has_mtl = False
+    mats = {"default_material": material_default()}
+    if mtl_line is not None:
+        rel = mtl_line[len("mtllib "):]
+        mats = load_mtl(rel if os.path.isabs(rel) else os.path.join(os.path.dirname(path), rel))
+        has_mtl = True
+    pos, tex, nrm, tris = [], [], [], []
+    active = 0
+    def read_index(s):
+        i = int(s) - 1
+        if i < 0:
+            raise ValueError("Tried to load negative indices from an OBJ file")
+        return i
+    def tri_from(groups):
+        t = dict(p=[0, 0, 0], t=[0, 0, 0], n=[0, 0, 0])
+        for g_id, g in enumerate(groups):
+            if "//" in g:
+                parts = g.split("//")
+                t["p"][g_id] = read_index(parts[0]); t["n"][g_id] = read_index(parts[1])
+            elif "/" in g:
+                parts = g.split("/")
+                if len(parts) == 2:
+                    t["p"][g_id] = read_index(parts[0]); t["t"][g_id] = read_index(parts[1])
+                elif len(parts) == 3:
+                    t["p"][g_id] = read_index(parts[0]); t["t"][g_id] = read_index(parts[1]); t["n"][g_id] = read_index(parts[2])
+            else:
+                t["p"][g_id] = read_index(g)
+        return t
+    for line in lines:
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] == "v":
+            d = [F(0)] * 3
+            for i, v in enumerate(tok[1:]):
+                d[i] = _parse_f32(v)
+            pos.append(d)
+        elif tok[0] == "vt":
+            d = [F(0)] * 2
+            for i, v in enumerate(tok[1:]):
+                d[i] = _parse_f32(v)
+            tex.append(d)
+        elif tok[0] == "vn":
+            d = [F(0)] * 3
+            for i, v in enumerate(tok[1:]):
+                d[i] = _parse_f32(v)
+            nrm.append(d)
+        elif tok[0] == "usemtl":
+            if has_mtl:
+                name = line[len("usemtl "):]
+                if name in mats:
+                    active = list(mats.keys()).index(name)
+        elif tok[0] == "f":
+            g = line[len("f "):].split()
+            if len(g) == 3:
+                new = [tri_from(g)]
+            elif len(g) == 4:
+                new = [tri_from([g[0], g[1], g[3]]), tri_from([g[1], g[2], g[3]])]
+            elif len(g) >= 5:
+                new = [tri_from([g[0], g[i + 1], g[i + 2]]) for i in range(len(g) - 2)]
+            else:
+                raise ValueError("face with fewer than 3 vertices")
+            for t in new:
+                t["m"] = active
+                tris.append(t)
+    if not nrm:                                             # obj.rs:107-120: one flat normal per triangle
+        with np.errstate(all="ignore"):
+            for i, t in enumerate(tris):
+                v1, v2, v3 = (vec(pos[t["p"][k]]) for k in range(3))
+                nrm.append(list(normalized(cross(v_sub(v2, v1), v_sub(v3, v1)))))
+                t["n"] = [i, i, i]
+    out = np.zeros(len(tris), dtype=L.TRIANGLE)
+    for k, t in enumerate(tris):                            # scene.rs:47-75: a missing index reads element 0, an absent buffer zeros
+        for i in range(3):
+            out[k]["vertices"][i]["position"] = pos[t["p"][i]] if t["p"][i] < len(pos) else [0, 0, 0]
+            tc = tex[t["t"][i]] if t["t"][i] < len(tex) else [0, 0]
+            out[k]["vertices"][i]["tex_coord_x"], out[k]["vertices"][i]["tex_coord_y"] = tc[0], tc[1]
+            out[k]["vertices"][i]["normal"] = nrm[t["n"][i]] if t["n"][i] < len(nrm) else [0, 0, 0]
+        out[k]["material_id"] = t["m"]
+    return out, list(mats.items())

@@ -75,3 +75,53 @@ def test_bvh_builder_second_reading(rrt, orc, kind, kw):
         assert a["first_tri_or_child"] == int(b["first_tri_or_child"]) and a["num_tris"] == int(b["num_tris"])
         assert np.array_equal(np.array(a["bounds_min"], np.float32) + 0.0, np.asarray(b["bounds_min"]) + 0.0)
         assert np.array_equal(np.array(a["bounds_max"], np.float32) + 0.0, np.asarray(b["bounds_max"]) + 0.0)
+
+
+def test_obj_to_bvh_second_reading(rrt, tmp_path):
+    """BASELINE configs[0] goes OBJ -> fat triangles -> BVH on the host.  That whole flatten, read a second time in Python
+    (loader/obj.rs, scene.rs:44-85, bvh.rs), against the C++ loader + builder of the product: identical triangle array
+    (order, positions, normals, uvs, material ids), node array and material table.  Materials are numbered in file order in
+    both (the reference numbers them in HashMap order, which is random per run and does not affect the image)."""
+    from oracle import pt_oracle_py as py
+    from rust_ray_tracing_amd import synth, _lib as L
+    files = [synth.write_cornell_obj(str(tmp_path))]
+    # a quirky file: quads, an n-gon, every index form, no vn (flat normals), missing vt on some faces, several materials,
+    # a usemtl that does not exist, decimal strings that need correct rounding
+    (tmp_path / "q.mtl").write_text("newmtl red\nKd 0.8 0.1 0.1\nKe 0 0 0\nNi 1.33\n\nnewmtl glow\nKd 0.30000001192092896 0.2 0.1\nKe 4.5 4.25 3.0000001\nd 0.5\n\n"
+                                    "newmtl lost\nKd 1 1 1\nnewmtl swallowed\nKd 0 0 0\n\nnewmtl last\nKd 0.1 0.9 0.1\nPr 0.25\nPm 1\nTf 0.7 0.7 0.7\n")
+    rng = np.random.default_rng(8)
+    v = rng.uniform(-2, 2, (40, 3))
+    body = ["mtllib q.mtl"] + [f"v {a:.7g} {b:.9g} {c}" for a, b, c in v] + [f"vt {a:.6f} {b:.6f}" for a, b in rng.uniform(0, 3, (12, 2))]
+    faces, k = [], 0
+    for form in ("{0}", "{0}/{1}", "{0}"):
+        for n in (3, 4, 5, 3, 6):
+            idx = [(k + j) % 40 + 1 for j in range(n)]
+            faces.append("f " + " ".join(form.format(i, (i % 12) + 1) for i in idx))
+            k += 3
+    body += ["usemtl red"] + faces[:5] + ["usemtl nope"] + faces[5:8] + ["usemtl last"] + faces[8:12] + ["usemtl glow"] + faces[12:]
+    (tmp_path / "q.obj").write_text("\n".join(body) + "\n")
+    files.append(str(tmp_path / "q.obj"))
+    # with normals and pos//normal, pos/tex/normal forms
+    body2 = [f"v {a:.7g} {b:.9g} {c}" for a, b, c in v[:12]] + [f"vn {a:.5f} {b:.5f} {c:.5f}" for a, b, c in rng.normal(0, 1, (5, 3))] + \
+            [f"vt {a:.6f} {b:.6f}" for a, b in rng.uniform(0, 1, (4, 2))] + \
+            ["f 1//1 2//2 3//3", "f 4/1/2 5/2/3 6/3/4 7/4/5", "f 8 9 10", "f 10/2 11/3 12/4"]
+    (tmp_path / "n.obj").write_text("\n".join(body2) + "\n")
+    files.append(str(tmp_path / "n.obj"))
+    for f in files:
+        sc = rrt.Scene.load(f)
+        assert sc is not None, f
+        tris, mats = py.load_obj(f)
+        t_py, n_py = py.build_bvh(tris)
+        assert np.array_equal(t_py.view(np.uint8), np.ascontiguousarray(sc.tris).view(np.uint8)), f
+        n_c = np.ascontiguousarray(sc.bvh_nodes).view(np.uint8).reshape(-1).view(L.NODE)
+        assert len(n_py) == len(n_c), f
+        for a, b in zip(n_py, n_c):
+            assert a["first_tri_or_child"] == int(b["first_tri_or_child"]) and a["num_tris"] == int(b["num_tris"])
+            assert np.array_equal(np.array(a["bounds_min"], np.float32) + 0.0, np.asarray(b["bounds_min"]) + 0.0)
+            assert np.array_equal(np.array(a["bounds_max"], np.float32) + 0.0, np.asarray(b["bounds_max"]) + 0.0)
+        assert [n for n, _ in mats] == list(sc.materials.keys()), f
+        for (name, m), got in zip(mats, sc.materials.values()):
+            for key in ("base_color", "specular_tint", "emission"):
+                assert np.array_equal(np.array(m[key], np.float32), np.asarray(got[key], np.float32)), (f, name, key)
+            for key in ("transmission", "ior", "roughness", "metallic", "transparency"):
+                assert np.float32(m[key]) == np.float32(got[key]), (f, name, key)
