@@ -503,3 +503,32 @@ def load_obj(path):
             out[k]["vertices"][i]["normal"] = nrm[t["n"][i]] if t["n"][i] < len(nrm) else [0, 0, 0]
         out[k]["material_id"] = t["m"]
     return out, list(mats.items())
+
+
+# ---- scene.rs:181-194 + mat4.rs:25-44 (host, once per frame; sin/cos are the platform libm's, as in the reference) -------
+def camera_from_pose(position, pitch_deg, yaw_deg):
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.sinf.restype = libm.cosf.restype = ctypes.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [ctypes.c_float]
+    sinf = lambda x: F(libm.sinf(ctypes.c_float(float(x))))
+    cosf = lambda x: F(libm.cosf(ctypes.c_float(float(x))))
+    rad = F(0.017453292519943295769236907684886)            # f32::to_radians multiplies by this constant
+    yaw, pitch = F(yaw_deg) * rad, F(pitch_deg) * rad
+    with np.errstate(all="ignore"):
+        direction = (cosf(yaw) * cosf(pitch), sinf(pitch), sinf(yaw) * cosf(pitch))
+        pos = vec(position)
+        forward = normalized(direction)
+        right = normalized(cross((F(0), F(1), F(0)), forward))
+        up = cross(forward, right)
+        # Mat4f::look_at(from = position, to = position + forward, up)
+        to = v_add(pos, forward)
+        f = normalized(v_sub(pos, to))
+        r = normalized(cross(up, f))
+        u = cross(f, r)
+    m = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        m[i][i] = 1
+    m[0][:3], m[1][:3], m[2][:3], m[3][:3] = r, u, f, pos
+    return m, np.array(pos, np.float32)

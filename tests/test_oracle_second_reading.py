@@ -125,3 +125,17 @@ def test_obj_to_bvh_second_reading(rrt, tmp_path):
                 assert np.array_equal(np.array(m[key], np.float32), np.asarray(got[key], np.float32)), (f, name, key)
             for key in ("transmission", "ior", "roughness", "metallic", "transparency"):
                 assert np.float32(m[key]) == np.float32(got[key]), (f, name, key)
+
+
+def test_camera_second_reading(rrt):
+    """Camera::update_view + Mat4f::look_at (scene.rs:181-194, mat4.rs:25-44) read a second time, against mipt_camera_from_pose."""
+    from oracle import pt_oracle_py as py
+    rng = np.random.default_rng(6)
+    poses = [((3.2, 0.0, 0.0), 0.0, 0.0), ((-11.2, 2.1, -0.12), 0.0, 0.0), ((0, 0, 0), 89.0, 180.0)]
+    poses += [(tuple(rng.uniform(-20, 20, 3)), float(rng.uniform(-89, 89)), float(rng.uniform(-360, 360))) for _ in range(40)]
+    for pos, pitch, yaw in poses:
+        cam = rrt.Camera(position=pos, pitch=pitch, yaw=yaw)
+        cam.update_view()
+        look, p = py.camera_from_pose(pos, pitch, yaw)
+        assert np.array_equal(np.asarray(cam.uniform["look_at"], np.float32).view(np.uint32), look.view(np.uint32)), (pos, pitch, yaw)
+        assert np.array_equal(np.asarray(cam.uniform["position"], np.float32), p)
