@@ -2,7 +2,7 @@
 rank-packed, ONE all-gather, de-interleave -- must reproduce the single-rank frame bit for bit, and the
 sample-sharded sum-reduce (config 5) must equal the rank-ordered sum of the per-rank partials.
 Pixels are produced by the CPU oracle here (no GPU in this container); the HIP kernel's own shard
-outputs are checked against the same index arithmetic in tests/test_gpu_sharding.py."""
+outputs are checked against the same index arithmetic in tests/test_gpu_more.py (test_tile_shards_reassemble_bit_exact)."""
 import os
 import sys
 
