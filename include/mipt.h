@@ -229,14 +229,6 @@ int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_de
 /* Material::default() (src/scene.rs:148-167). */
 void mipt_material_default(MiptMaterial *out);
 
-/* Diagnostic: evaluates one device arithmetic primitive element-wise on the GPU (host buffers in/out),
- * so tests can pin the kernel's f32/f64 building blocks against the oracle bit for bit.
- * op: 0 cos-shim, 1 log10-shim, 2 pow-shim(a,b), 3 a/b, 4 sqrt(a), 5 a*b, 6 a+b, 7 min, 8 max,
- *     9 rand_f32(seed=bits(a)), 10 rand_f32_nd(seed), 11 rand_in_unit_sphere(seed)[b], 12 srgb+quantise(a)
- *     (result as integer bits), 13 fract(a), 14 the per-ray-reciprocal division a/b (valid on its checked range),
- *     15 u8 -> f32/255 for the integer whose bits are a. */
-int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out);
-
 const char *mipt_last_error(void);
 int mipt_abi_version(void);
 /* number of HIP devices visible, or a negative MiptStatus */

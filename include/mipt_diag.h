@@ -1,0 +1,35 @@
+/*
+ * mipt_diag.h -- diagnostic probe library (libmipt_diag.so).  Test infrastructure for the GPU box; NOT part of the
+ * drop-in boundary (include/mipt.h) and not exported by libmipt.so.
+ *
+ * Evaluates one device arithmetic primitive of the path-tracing kernel element-wise on the GPU, so tests can pin the
+ * kernel's f32/f64 building blocks against the CPU oracle bit for bit.  The functions evaluated are the very ones the
+ * kernel inlines (rust_ray_tracing_amd/csrc/pt_device_math.h): the restatement of glibc 2.35's cosf / log10f / powf
+ * that stands in for Rust std f32::cos / f32::log10 / f32::powf (reference src/math.rs:15-19, src/math/vec3.rs:80-90).
+ */
+#ifndef MIPT_DIAG_H
+#define MIPT_DIAG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* host buffers in/out.  op: 0 cosf, 1 log10f, 2 powf(a,b), 3 a/b, 4 sqrt(a), 5 a*b, 6 a+b, 7 min, 8 max,
+ *     9 rand_f32(seed=bits(a)), 10 rand_f32_nd(seed), 11 rand_in_unit_sphere(seed)[b], 12 srgb+quantise(a)
+ *     (result as integer bits), 13 fract(a), 14 the per-ray-reciprocal division a/b (valid on its checked range),
+ *     15 u8 -> f32/255 for the integer whose bits are a, 16 sinf, 17 expf, 18 logf.
+ * Returns 0, or -1 (bad argument) / -2 (HIP error); device buffers are released on every path. */
+int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out);
+
+/* ops 0, 1, 2 (with second argument y), 16, 17, 18 on the n consecutive binary32 bit patterns first_bits, first_bits+1, ...
+ * (first_bits + n <= 2^32): the exhaustive sweeps of tests/test_gpu_libm.py. */
+int mipt_debug_eval_range(int op, uint32_t first_bits, uint64_t n, float y, float *out);
+
+const char *mipt_diag_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_DIAG_H */

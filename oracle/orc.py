@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
 
 SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
-LIBM_SHIM, LIBM_HOST = 0, 1
+LIBM_GLIBC235, LIBM_HOST = 0, 1   # restated glibc 2.35 (kernel's spec) / this process's libm
 
 
 class OrcTexture(C.Structure):
@@ -82,11 +82,13 @@ def load() -> C.CDLL:
     lib.orc_texture_color_at.restype = None
     lib.orc_pixel_screen.argtypes = [u32, u32, u32, C.POINTER(f32 * 2)]
     lib.orc_pixel_screen.restype = None
-    for name in ("orc_shim_cosf", "orc_shim_log10f", "orc_shim_sinf", "orc_shim_expf"):
+    for name in ("orc_glibc_cosf", "orc_glibc_log10f", "orc_glibc_sinf", "orc_glibc_expf", "orc_glibc_logf"):
         getattr(lib, name).argtypes = [f32]
         getattr(lib, name).restype = f32
-    lib.orc_shim_powf.argtypes = [f32, f32]
-    lib.orc_shim_powf.restype = f32
+    lib.orc_glibc_powf.argtypes = [f32, f32]
+    lib.orc_glibc_powf.restype = f32
+    lib.orc_eval_array.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp]
+    lib.orc_eval_array.restype = None
     lib.orc_postprocess.argtypes = [vp, C.c_uint64, f32, C.c_int, vp]
     lib.orc_postprocess.restype = None
     lib.orc_trace_ray.argtypes = [vp, u32, vp, u32, vp, u32, C.POINTER(OrcTexture), u32, C.POINTER(f32 * 3), C.POINTER(f32 * 3),
@@ -96,7 +98,29 @@ def load() -> C.CDLL:
     return lib
 
 
-def postprocess(hdr, divisor=1.0, libm=LIBM_SHIM):
+def eval_array(op, a, b=None, libm=LIBM_GLIBC235, threads=1):
+    """cosf (op 0) / log10f (1) / powf(a, b) (2) / sinf (16) / expf (17) / logf (18) over an f32 array: the glibc 2.35
+    restatement (default) or this process's libm.  threads > 1 splits the array (ctypes releases the GIL)."""
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    bb = None if b is None else np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=np.float32), a.shape))
+    out = np.empty_like(a)
+    f = load().orc_eval_array
+
+    def part(lo, hi):
+        if hi > lo:
+            f(op, libm, a[lo:hi].ctypes.data, None if bb is None else bb[lo:hi].ctypes.data, hi - lo, out[lo:hi].ctypes.data)
+    threads = max(1, min(int(threads), 64))
+    if threads == 1 or a.size < (1 << 16):
+        part(0, a.size)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [a.size * i // threads for i in range(threads + 1)]
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: part(cuts[i], cuts[i + 1]), range(threads)))
+    return out
+
+
+def postprocess(hdr, divisor=1.0, libm=LIBM_GLIBC235):
     """pp_compute.wgsl on an [h,w,3] f32 frame -> [h,w,4] uint16."""
     hdr = np.ascontiguousarray(hdr, dtype=np.float32)
     out = np.zeros(hdr.shape[:-1] + (4,), dtype=np.uint16)
@@ -131,7 +155,7 @@ def camera_from_pose(position, pitch, yaw) -> np.ndarray:
 
 
 def render(tris, nodes, materials, textures, camera, width, height, samples, max_ray_depth, *, seed_mode=0, cull=0,
-           libm=LIBM_SHIM, threads=0, pix_begin=0, pix_end=0, pix_stride=0, sample_begin=0, sum_only=0, stack_cap=0,
+           libm=LIBM_GLIBC235, threads=0, pix_begin=0, pix_end=0, pix_stride=0, sample_begin=0, sum_only=0, stack_cap=0,
            cull_margin=0.0, shading=0, want_rgba8=True):
     """Returns (hdr [h,w,3] f32, rgba8 [h,w,4] u8 | None, stats dict).  Arrays may be any dtype of the right byte size."""
     tris = np.ascontiguousarray(tris)

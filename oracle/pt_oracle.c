@@ -38,160 +38,61 @@ _Static_assert(__builtin_offsetof(OrcCamera, position) == 64, "UniformCamera.pos
 #define ORC_F32_MAX 3.40282346638528859812e+38f
 
 /* ------------------------------------------------------------------------- */
-/* Deterministic transcendental shim.                                         */
-/* The reference calls Rust std f32::{cos,log10,powf} = the platform libm     */
-/* (math.rs:16-18, vec3.rs:87).  libm's last-ulp results are not reproducible */
-/* on a GPU, so oracle and kernel both evaluate the functions below: IEEE     */
-/* binary64 + - * / only, fixed order, no FMA, result rounded once to f32.    */
-/* The kernel carries its own copy of this spec (csrc/mipt_device_math.h).    */
+/* Transcendentals.  The reference calls Rust std f32::{cos,log10,powf} = the */
+/* platform libm (math.rs:16-18, vec3.rs:87), i.e. glibc on Linux.            */
+/* ORC_LIBM_GLIBC235 (default): the restatement of glibc 2.35's algorithms in */
+/* glibc_flt32.h (x86_64 FMA variants) -- the same spec the kernel carries in */
+/* csrc/pt_device_math.h; tests/test_libm_pin.py proves it equal to this      */
+/* machine's libm on every binary32 argument.  ORC_LIBM_HOST: call the libm   */
+/* this process is linked to (what the Rust binary would do); kept so tests   */
+/* can assert that whole renders are bit-identical either way.                */
 /* ------------------------------------------------------------------------- */
+#include "glibc_flt32.h"
 static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 
-static double shim_ksin(double r) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = S6;
-    p = S5 + z * p; p = S4 + z * p; p = S3 + z * p; p = S2 + z * p; p = S1 + z * p;
-    return r + (r * z) * p;
-}
-static double shim_kcos(double r) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = r * r;
-    double p = C6;
-    p = C5 + z * p; p = C4 + z * p; p = C3 + z * p; p = C2 + z * p; p = C1 + z * p;
-    return (1.0 - 0.5 * z) + (z * z) * p;
-}
-float orc_shim_cosf(float x) {
-    if (!(fabsf(x) <= 1048576.0f)) {             /* NaN, inf, or out of the shim's range */
-        return x - x;                            /* NaN for inf/NaN; callers stay within range */
+float orc_glibc_cosf(float x) { return gl_cosf(x); }
+float orc_glibc_sinf(float x) { return gl_sinf(x); }
+float orc_glibc_logf(float x) { return gl_logf(x); }
+float orc_glibc_log10f(float x) { return gl_log10f(x); }
+float orc_glibc_expf(float x) { return gl_expf(x); }
+float orc_glibc_powf(float x, float y) { return gl_powf(x, y); }
+/* array forms for the sweep tests: op 0 cosf, 1 log10f, 2 powf(a, b), 16 sinf, 17 expf, 18 logf (the op numbers of
+ * mipt_debug_eval); libm selects the restatement or the host libm */
+void orc_eval_array(int op, int libm, const float *a, const float *b, uint64_t n, float *out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        float r = 0.0f;
+        if (libm == ORC_LIBM_HOST) {
+            switch (op) {
+            case 0: r = cosf(x); break;
+            case 1: r = log10f(x); break;
+            case 2: r = powf(x, y); break;
+            case 16: r = sinf(x); break;
+            case 17: r = expf(x); break;
+            case 18: r = logf(x); break;
+            default: break;
+            }
+        } else {
+            switch (op) {
+            case 0: r = gl_cosf(x); break;
+            case 1: r = gl_log10f(x); break;
+            case 2: r = gl_powf(x, y); break;
+            case 16: r = gl_sinf(x); break;
+            case 17: r = gl_expf(x); break;
+            case 18: r = gl_logf(x); break;
+            default: break;
+            }
+        }
+        out[i] = r;
     }
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    const double PIO2_1 = 1.57079632673412561417e+00;   /* first 33 bits of pi/2 */
-    const double PIO2_1T = 6.07710050650619224932e-11;  /* pi/2 - PIO2_1 */
-    double xd = (double)x;
-    double kf = floor(xd * INV_PIO2 + 0.5);
-    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
-    long long k = (long long)kf;
-    double c;
-    switch (k & 3) {
-    case 0: c = shim_kcos(r); break;
-    case 1: c = -shim_ksin(r); break;
-    case 2: c = -shim_kcos(r); break;
-    default: c = shim_ksin(r); break;
-    }
-    return (float)c;
 }
 
-/* ln(m) for xd = m * 2^e, m in [sqrt(1/2), sqrt(2)); xd positive, finite, normal */
-static double shim_log_reduce(double xd, double *e_out) {
-    const double SQRT2 = 1.41421356237309514547e+00;
-    uint64_t b = d2u(xd);
-    int e = (int)((b >> 52) & 0x7ff) - 1023;
-    double m = u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-    if (m > SQRT2) { m = m * 0.5; e += 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double p = 4.34782608695652161754e-02;            /* 1/23 */
-    p = 4.76190476190476164085e-02 + z * p;           /* 1/21 */
-    p = 5.26315789473684181249e-02 + z * p;           /* 1/19 */
-    p = 5.88235294117647050660e-02 + z * p;           /* 1/17 */
-    p = 6.66666666666666657415e-02 + z * p;           /* 1/15 */
-    p = 7.69230769230769273453e-02 + z * p;           /* 1/13 */
-    p = 9.09090909090909116141e-02 + z * p;           /* 1/11 */
-    p = 1.11111111111111104943e-01 + z * p;           /* 1/9  */
-    p = 1.42857142857142849213e-01 + z * p;           /* 1/7  */
-    p = 2.00000000000000011102e-01 + z * p;           /* 1/5  */
-    p = 3.33333333333333314830e-01 + z * p;           /* 1/3  */
-    p = 1.0 + z * p;
-    *e_out = (double)e;
-    return (2.0 * s) * p;
-}
-float orc_shim_log10f(float x) {
-    if (x != x) return x;
-    if (x < 0.0f) return (x - x) / (x - x);            /* NaN */
-    if (x == 0.0f) return -INFINITY;
-    if (x == INFINITY) return x;
-    const double LOG10_2 = 3.01029995663981198017e-01;
-    const double INV_LN10 = 4.34294481903251816668e-01;
-    double e, lm = shim_log_reduce((double)x, &e);
-    return (float)(e * LOG10_2 + lm * INV_LN10);
-}
-static double shim_exp(double z) {                    /* z in [-110, 100] */
-    const double INV_LN2 = 1.44269504088896338700e+00;
-    const double LN2_HI = 6.93147180369123816490e-01;
-    const double LN2_LO = 1.90821492927058770002e-10;
-    double kf = floor(z * INV_LN2 + 0.5);
-    double r = (z - kf * LN2_HI) - kf * LN2_LO;
-    double p = 1.60590438368216133e-10;               /* 1/13! */
-    p = 2.08767569878680989792e-09 + r * p;           /* 1/12! */
-    p = 2.50521083854417187751e-08 + r * p;           /* 1/11! */
-    p = 2.75573192239858906526e-07 + r * p;           /* 1/10! */
-    p = 2.75573192239858906526e-06 + r * p;           /* 1/9!  */
-    p = 2.48015873015873015873e-05 + r * p;           /* 1/8!  */
-    p = 1.98412698412698412698e-04 + r * p;           /* 1/7!  */
-    p = 1.38888888888888894189e-03 + r * p;           /* 1/6!  */
-    p = 8.33333333333333321769e-03 + r * p;           /* 1/5!  */
-    p = 4.16666666666666643537e-02 + r * p;           /* 1/4!  */
-    p = 1.66666666666666657415e-01 + r * p;           /* 1/3!  */
-    p = 0.5 + r * p;
-    p = 1.0 + r * p;
-    p = 1.0 + r * p;
-    long long k = (long long)kf;
-    double scale = u2d((uint64_t)(k + 1023) << 52);
-    return p * scale;
-}
-float orc_shim_powf(float x, float y) {
-    if (y == 0.0f || x == 1.0f) return 1.0f;
-    if (x != x || y != y) return x + y;
-    if (x < 0.0f) return (x - x) / (x - x);           /* NaN: the path never raises a negative to an integer */
-    if (x == 0.0f) return y > 0.0f ? 0.0f : INFINITY;
-    if (x == INFINITY) return y > 0.0f ? INFINITY : 0.0f;
-    if (y == INFINITY) return x > 1.0f ? INFINITY : 0.0f;
-    if (y == -INFINITY) return x > 1.0f ? 0.0f : INFINITY;
-    const double LN2 = 6.93147180559945286227e-01;
-    double e, lm = shim_log_reduce((double)x, &e);
-    double z = (double)y * (e * LN2 + lm);
-    if (z > 100.0) return INFINITY;
-    if (z < -110.0) return 0.0f;
-    return (float)shim_exp(z);
-}
-
-float orc_shim_sinf(float x) {                     /* same reduction as orc_shim_cosf; sin(x) = {s, c, -s, -c}[k & 3] */
-    if (!(fabsf(x) <= 1048576.0f)) return x - x;
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    const double PIO2_1 = 1.57079632673412561417e+00;
-    const double PIO2_1T = 6.07710050650619224932e-11;
-    double xd = (double)x;
-    double kf = floor(xd * INV_PIO2 + 0.5);
-    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
-    long long k = (long long)kf;
-    double v;
-    switch (k & 3) {
-    case 0: v = shim_ksin(r); break;
-    case 1: v = shim_kcos(r); break;
-    case 2: v = -shim_ksin(r); break;
-    default: v = -shim_kcos(r); break;
-    }
-    return (float)v;
-}
-float orc_shim_expf(float x) {
-    if (x != x) return x;
-    if (x > 100.0f) return INFINITY;
-    if (x < -110.0f) return 0.0f;
-    return (float)shim_exp((double)x);
-}
-
-static inline float f_cos(float x, int libm)   { return libm == ORC_LIBM_HOST ? cosf(x) : orc_shim_cosf(x); }
-static inline float f_log10(float x, int libm) { return libm == ORC_LIBM_HOST ? log10f(x) : orc_shim_log10f(x); }
-static inline float f_pow(float x, float y, int libm) { return libm == ORC_LIBM_HOST ? powf(x, y) : orc_shim_powf(x, y); }
-static inline float f_sin(float x, int libm)   { return libm == ORC_LIBM_HOST ? sinf(x) : orc_shim_sinf(x); }
-static inline float f_exp(float x, int libm)   { return libm == ORC_LIBM_HOST ? expf(x) : orc_shim_expf(x); }
+static inline float f_cos(float x, int libm)   { return libm == ORC_LIBM_HOST ? cosf(x) : gl_cosf(x); }
+static inline float f_log10(float x, int libm) { return libm == ORC_LIBM_HOST ? log10f(x) : gl_log10f(x); }
+static inline float f_pow(float x, float y, int libm) { return libm == ORC_LIBM_HOST ? powf(x, y) : gl_powf(x, y); }
+static inline float f_sin(float x, int libm)   { return libm == ORC_LIBM_HOST ? sinf(x) : gl_sinf(x); }
+static inline float f_exp(float x, int libm)   { return libm == ORC_LIBM_HOST ? expf(x) : gl_expf(x); }
 
 /* ------------------------------------------------------------------------- */
 /* math.rs / vec3.rs / vec2.rs / mat4.rs subset                               */
@@ -479,7 +380,7 @@ static v3 trace(Ray *ray, uint32_t max_bounces, const SceneView *sc, uint32_t *r
 /* (shading mode 1).  The reference has no CPU oracle for  */
 /* it and WGSL leaves much to the implementation (FMA fusion, the precision of */
 /* pow/exp/sin/cos/inverseSqrt, the bilinear filter's weights): this is ONE    */
-/* deterministic reading -- one rounded f32 op per operator, the shim for the  */
+/* deterministic reading -- one rounded f32 op per operator, the glibc restatement for the  */
 /* transcendentals, exact f32 bilinear weights -- shared with the kernel.      */
 /* "parity unpinned" against a real GPU run.                                   */
 /* ------------------------------------------------------------------------- */

@@ -66,8 +66,8 @@ typedef struct {                                              /* texture.rs:4-10
 
 enum { ORC_SEED_PIXEL_STREAM = 0,   /* cpu.rs:28-29           */
        ORC_SEED_PER_SAMPLE   = 1 }; /* rt_compute.wgsl:102    */
-enum { ORC_LIBM_SHIM = 0,           /* deterministic cos/log10/pow (shared spec with the kernel) */
-       ORC_LIBM_HOST = 1 };         /* glibc cosf/log10f/powf = what the Rust binary would call  */
+enum { ORC_LIBM_GLIBC235 = 0,       /* restated glibc 2.35 cosf/log10f/powf (same spec as the kernel) */
+       ORC_LIBM_HOST = 1 };         /* this process's libm = what the Rust binary would call     */
 
 typedef struct {
     uint32_t width, height;          /* renderer.rs:100 output_image_dimensions */
@@ -140,11 +140,13 @@ void     orc_linear_to_srgb(const float in[3], int libm, float out[3]);  /* vec3
 void     orc_quantize(const float in[3], uint8_t out[3]);       /* vec3.rs:262-270 */
 void     orc_texture_color_at(const OrcTexture *t, float u, float v, uint8_t out[4]); /* texture.rs:33-38 */
 void     orc_pixel_screen(uint32_t index, uint32_t w, uint32_t h, float out[2]); /* cpu.rs:31-35 */
-float    orc_shim_cosf(float x);
-float    orc_shim_log10f(float x);
-float    orc_shim_powf(float x, float y);
-float    orc_shim_sinf(float x);
-float    orc_shim_expf(float x);
+float    orc_glibc_cosf(float x);
+float    orc_glibc_sinf(float x);
+float    orc_glibc_logf(float x);
+float    orc_glibc_log10f(float x);
+float    orc_glibc_expf(float x);
+float    orc_glibc_powf(float x, float y);
+void     orc_eval_array(int op, int libm, const float *a, const float *b, uint64_t n, float *out);
 /* trace one explicit ray (ray.rs:141-202); returns radiance in out[3] */
 void     orc_trace_ray(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
                        const OrcMaterial *materials, uint32_t n_materials,

@@ -4,7 +4,7 @@ Written from the Rust sources again, in pure Python over numpy float32 scalars (
 operator), for SMALL cases only (a few hundred pixels): tests/test_oracle_second_reading.py requires it to agree bit for bit
 with the C oracle (pt_oracle.c), so that a misreading of the reference in one restatement does not go unnoticed.  Like the
 C oracle it is "parity unpinned" against the real Rust binary (no Rust toolchain here, the reference has no tests or
-fixtures); cos / log10 / powf go through the same deterministic binary64 shim specification (restated below).
+fixtures); cos / log10 are calls into the platform libm (glibc), exactly as in the Rust binary.
 
 Reference lines followed: src/renderer/backend/cpu.rs:13-68, src/renderer/backend/cpu/ray.rs:19-227, src/math.rs:6-24,
 src/math/vec3.rs:66-109,130-205,252-366, src/math/mat4.rs:143-152, src/texture.rs:33-38, src/bvh.rs:13-203,
@@ -21,66 +21,25 @@ F32_MAX = F(3.4028234663852886e38)
 MISS = F(1e30)
 
 
-# ---- the transcendental shim (binary64 + - * / only, fixed order, one final rounding to binary32) -------------------
-def _ksin(r):
-    z = r * r
-    p = 1.58969099521155010221e-10
-    for c in (-2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04, 8.33333333332248946124e-03,
-              -1.66666666666666324348e-01):
-        p = c + z * p
-    return r + (r * z) * p
+# ---- cos / log10: the platform libm itself -----------------------------------------------------------------------------
+# Rust std's f32::cos / f32::log10 (math.rs:16-18) are calls into the platform libm; this reading makes the same calls
+# (glibc's cosf / log10f through ctypes) instead of restating them, so agreement with the C oracle -- which evaluates its
+# glibc 2.35 restatement, oracle/glibc_flt32.h -- also checks that restatement on every argument these renders produce.
+import ctypes as _C
+
+_libm = _C.CDLL("libm.so.6")
+_libm.cosf.restype = _C.c_float
+_libm.cosf.argtypes = [_C.c_float]
+_libm.log10f.restype = _C.c_float
+_libm.log10f.argtypes = [_C.c_float]
 
 
-def _kcos(r):
-    z = r * r
-    p = -1.13596475577881948265e-11
-    for c in (2.08757232129817482790e-09, -2.75573143513906633035e-07, 2.48015872894767294178e-05, -1.38888888888741095749e-03,
-              4.16666666666666019037e-02):
-        p = c + z * p
-    return (1.0 - 0.5 * z) + (z * z) * p
+def libm_cosf(x):
+    return F(_libm.cosf(float(F(x))))
 
 
-def shim_cosf(x):
-    x = float(x)
-    if not abs(x) <= 1048576.0:
-        return F(x - x)
-    kf = math.floor(x * 6.36619772367581382433e-01 + 0.5)
-    r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11
-    k = int(kf) & 3
-    s, c = _ksin(r), _kcos(r)
-    return F((c, -s, -c, s)[k])
-
-
-def _log_reduce(xd):
-    bits = struct.unpack("<Q", struct.pack("<d", xd))[0]
-    e = ((bits >> 52) & 0x7FF) - 1023
-    m = struct.unpack("<d", struct.pack("<Q", (bits & 0x000FFFFFFFFFFFFF) | 0x3FF0000000000000))[0]
-    if m > 1.41421356237309514547e+00:
-        m = m * 0.5
-        e += 1
-    f = m - 1.0
-    s = f / (2.0 + f)
-    z = s * s
-    p = 4.34782608695652161754e-02
-    for c in (4.76190476190476164085e-02, 5.26315789473684181249e-02, 5.88235294117647050660e-02, 6.66666666666666657415e-02,
-              7.69230769230769273453e-02, 9.09090909090909116141e-02, 1.11111111111111104943e-01, 1.42857142857142849213e-01,
-              2.00000000000000011102e-01, 3.33333333333333314830e-01, 1.0):
-        p = c + z * p
-    return (2.0 * s) * p, float(e)
-
-
-def shim_log10f(x):
-    x = F(x)
-    if x != x:
-        return x
-    if x < 0:
-        return F(np.nan)
-    if x == 0:
-        return F(-np.inf)
-    if x == F(np.inf):
-        return x
-    lm, e = _log_reduce(float(x))
-    return F(e * 3.01029995663981198017e-01 + lm * 4.34294481903251816668e-01)
+def libm_log10f(x):
+    return F(_libm.log10f(float(F(x))))
 
 
 # pow is only needed by the sRGB epilogue; it is taken from the C oracle's known-answer entry point in the test instead of
@@ -103,8 +62,8 @@ def rand_f32(s):                                            # math.rs:22-24 (u32
 
 def rand_f32_nd(s):                                         # math.rs:15-19
     theta = F(6.283185) * rand_f32(s)
-    rho = np.sqrt(F(-2.0) * shim_log10f(rand_f32(s)))
-    return F(rho * shim_cosf(theta))
+    rho = np.sqrt(F(-2.0) * libm_log10f(rand_f32(s)))
+    return F(rho * libm_cosf(theta))
 
 
 def v_add(a, b): return (a[0] + b[0], a[1] + b[1], a[2] + b[2])

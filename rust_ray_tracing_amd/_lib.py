@@ -72,7 +72,7 @@ EXPORTS = [
     "mipt_scene_create", "mipt_scene_destroy", "mipt_render", "mipt_render_device",
     "mipt_packed_pixels", "mipt_unpack_tiles", "mipt_tonemap_device", "mipt_postprocess_device", "mipt_bvh_build", "mipt_bvh_build_device",
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
-    "mipt_device_count", "mipt_debug_eval", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
+    "mipt_device_count", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
     "mipt_texture_load", "mipt_texture_free", "mipt_image_save_png",
 ]
 
@@ -125,8 +125,6 @@ def load() -> C.CDLL:
     lib.mipt_abi_version.restype = C.c_int
     lib.mipt_device_count.argtypes = []
     lib.mipt_device_count.restype = C.c_int
-    lib.mipt_debug_eval.argtypes = [C.c_int, vp, vp, u64, vp]
-    lib.mipt_debug_eval.restype = C.c_int
     lib.mipt_obj_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.mipt_obj_load.restype = C.c_int
     lib.mipt_obj_free.argtypes = [vp]
@@ -140,6 +138,32 @@ def load() -> C.CDLL:
     lib.mipt_image_save_png.argtypes = [C.c_char_p, u32, u32, u32, vp]
     lib.mipt_image_save_png.restype = C.c_int
     _lib = lib
+    return lib
+
+
+DIAG_LIB_PATH = os.path.join(_HERE, "libmipt_diag.so")
+DIAG_EXPORTS = ["mipt_debug_eval", "mipt_debug_eval_range", "mipt_diag_last_error"]
+_diag = None
+
+
+def load_diag() -> C.CDLL:
+    """libmipt_diag.so (include/mipt_diag.h): the device-arithmetic probe the GPU known-answer tests use.  Test
+    infrastructure; the product library exports none of it."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    load()
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise ImportError(f"{DIAG_LIB_PATH} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(DIAG_LIB_PATH)
+    vp = C.c_void_p
+    lib.mipt_debug_eval.argtypes = [C.c_int, vp, vp, C.c_uint64, vp]
+    lib.mipt_debug_eval.restype = C.c_int
+    lib.mipt_debug_eval_range.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_float, vp]
+    lib.mipt_debug_eval_range.restype = C.c_int
+    lib.mipt_diag_last_error.argtypes = []
+    lib.mipt_diag_last_error.restype = C.c_char_p
+    _diag = lib
     return lib
 
 

@@ -390,10 +390,12 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
     pr.cull_scale = 1.0f + opt->cull_margin;
     pr.service_num = 1; pr.service_den = 4; pr.reverse_tiles = 0;
     pr.lds_top = 0;
+#ifdef MIPT_TUNING   // experiment knobs exist only in a `make TUNING=1` build (tools/README.md); the product reads no environment
     if (const char *e = getenv("MIPT_LDS_TOP")) pr.lds_top = atoi(e) ? 1u : 0u;
     if (const char *e = getenv("MIPT_REVERSE_TILES")) pr.reverse_tiles = atoi(e) ? 1u : 0u;
     if (const char *e = getenv("MIPT_SERVICE_NUM")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_num = (uint32_t)v; }
     if (const char *e = getenv("MIPT_SERVICE_DEN")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_den = (uint32_t)v; }
+#endif
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) pr.cam[c * 3 + r] = camera->look_at[c][r];
     pr.cam[9] = camera->position.x; pr.cam[10] = camera->position.y; pr.cam[11] = camera->position.z;
@@ -412,7 +414,9 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
         const int cap = (int)(fit < 2 ? 2 : fit);
         if (cap < bpc) bpc = cap;
     }
+#ifdef MIPT_TUNING
     if (const char *env = getenv("MIPT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) bpc = v < occ ? v : occ; }
+#endif
     long long grid = (long long)scene->n_cu * bpc;
     const long long need_blocks = (long long)((pr.total_work + mipt::kBlockThreads - 1) / mipt::kBlockThreads);
     if (grid > need_blocks) grid = need_blocks;
@@ -495,19 +499,6 @@ int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor
 int mipt_postprocess_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint16_t *d_rgba16, void *hip_stream) {
     if (!d_hdr_rgb || !d_rgba16 || n_pixels == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_postprocess_device: bad argument");
     HIP_TRY(mipt::launch_postprocess(d_hdr_rgb, n_pixels, divisor, d_rgba16, (hipStream_t)hip_stream));
-    return MIPT_OK;
-}
-
-int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out) {
-    if (!a || !out || n == 0) return fail(MIPT_ERR_INVALID_ARG, "mipt_debug_eval: bad argument");
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void **)&da, n * 4));
-    HIP_TRY(hipMalloc((void **)&dout, n * 4));
-    HIP_TRY(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
-    if (b) { HIP_TRY(hipMalloc((void **)&db, n * 4)); HIP_TRY(hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice)); }
-    HIP_TRY(mipt::launch_debug_eval(op, da, db, n, dout, nullptr));
-    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
     return MIPT_OK;
 }
 

@@ -1,6 +1,6 @@
 // pt_device_math.h -- gfx950 device arithmetic for the path tracer.
 //
-// Every function is one IEEE-754 binary32 (or, in the transcendental shim, binary64)
+// Every function is one IEEE-754 binary32 (or, in the libm restatement, binary64)
 // operation per source operator, evaluated in the order of the reference's Rust source;
 // (note: __builtin_sqrtf is the correctly-rounded expansion; __fsqrt_rn lowers to the 1-ulp v_sqrt_f32)
 // the translation unit is built with -ffp-contract=off so hipcc never fuses a*b+c (Rust
@@ -39,169 +39,316 @@ __device__ __forceinline__ uint32_t xor_shift(uint32_t &s) {
 // math.rs:22-24 -- u32::MAX as f32 == 2^32; v_cvt_f32_u32 rounds to nearest even like `as f32`
 __device__ __forceinline__ float rand_f32(uint32_t &s) { return (float)xor_shift(s) / 4294967296.0f; }
 
-// ---- deterministic transcendental shim (same spec as the CPU oracle's) ----
-// IEEE binary64 + - * / only, fixed order, result rounded once to binary32.
-__device__ __forceinline__ double shim_ksin(double r) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = S6;
-    p = S5 + z * p; p = S4 + z * p; p = S3 + z * p; p = S2 + z * p; p = S1 + z * p;
-    return r + (r * z) * p;
+// ---- glibc 2.35 binary32 transcendentals, restated for gfx950 ------------------------------------------------------
+// The reference's CPU backend calls Rust std f32::cos / f32::log10 (src/math.rs:15-19) and f32::powf
+// (src/math/vec3.rs:87); Rust forwards them to the platform libm = glibc.  These are glibc 2.35's algorithms
+// (sysdeps/ieee754/flt-32/{s_cosf.c, s_sinf.c, s_sincosf.h, e_logf.c, e_log10f.c, e_powf.c, e_expf.c}) in the form the
+// x86_64 build executes on an FMA-capable CPU -- the *_fma IFUNC variants, in which gcc fused every a*b+c of those
+// files (read off the disassembly of libm.so.6, Ubuntu GLIBC 2.35-0ubuntu3.11).  Each __builtin_fma below is one
+// vfmadd of that binary = one v_fma_f64 here; everything else is one rounded IEEE operation; the translation unit is
+// built with -ffp-contract=off so nothing else fuses.  Tables: glibc_flt32_data.h (generated from that libm).
+// Pinned: tests/test_libm_pin.py (CPU restatement == the machine's libm on every binary32 of the path's domains) and
+// tests/test_gpu_libm.py (these device functions == the CPU restatement on the same sweeps).
+#define GLIBC_FLT32_TABLE static __device__ const
+#include "glibc_flt32_data.h"
+
+__device__ __forceinline__ double gl_d(const uint64_t *t, int i) { return __longlong_as_double((long long)t[i]); }
+__device__ __forceinline__ uint32_t gl_abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+__device__ __forceinline__ float gl_invalidf(float x) { return (x - x) / (x - x); }
+
+// s_sincosf.h sinf_poly.  x86 table layout: sign[4] @0, hpi_inv @4, hpi @5, c0 @6, c1 @7, s1 @8, c2 @9, s2 @10,
+// c3 @11, s3 @12, c4 @13.  __sincosf_table[1] (used when n & 2) holds the same sine coefficients and the negated
+// cosine coefficients, and the cosine polynomial reads x only through x2: so table[1]'s cosine result is the exact
+// negation of table[0]'s (negation commutes with every rounding) and its sine result is table[0]'s -- no second table.
+__device__ __forceinline__ double gl_sin_poly(double x, double x2) {
+    const uint64_t *p = glibc_sincosf_tab;
+    const double x3 = x * x2;
+    const double s1 = __builtin_fma(x2, gl_d(p, 12), gl_d(p, 10));   // s2 + x2*s3
+    const double x7 = x3 * x2;
+    const double s = __builtin_fma(x3, gl_d(p, 8), x);               // x + x3*s1
+    return __builtin_fma(s1, x7, s);                                 // s + x7*s1
 }
-__device__ __forceinline__ double shim_kcos(double r) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = r * r;
-    double p = C6;
-    p = C5 + z * p; p = C4 + z * p; p = C3 + z * p; p = C2 + z * p; p = C1 + z * p;
-    return (1.0 - 0.5 * z) + (z * z) * p;
+__device__ __forceinline__ double gl_cos_poly(double x2) {
+    const uint64_t *p = glibc_sincosf_tab;
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, gl_d(p, 13), gl_d(p, 11));   // c3 + x2*c4
+    const double c1 = __builtin_fma(x2, gl_d(p, 7), gl_d(p, 6));     // c0 + x2*c1
+    const double x6 = x4 * x2;
+    const double c = __builtin_fma(x4, gl_d(p, 9), c1);              // c1 + x4*c2
+    return __builtin_fma(c2, x6, c);                                 // c + x6*c2
 }
-__device__ __noinline__ float shim_cosf(float x) {
-    if (!(fabsf(x) <= 1048576.0f)) return x - x;
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    const double PIO2_1 = 1.57079632673412561417e+00;
-    const double PIO2_1T = 6.07710050650619224932e-11;
-    double xd = (double)x;
-    double kf = floor(xd * INV_PIO2 + 0.5);
-    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
-    long long k = (long long)kf;
-    double s = shim_ksin(r), c = shim_kcos(r);
-    double v;
-    switch (k & 3) {
-    case 0: v = c; break;
-    case 1: v = -s; break;
-    case 2: v = -c; break;
-    default: v = s; break;
+// reduce_fast (|x| < 120) / reduce_large (integer multiplication by 4/pi); returns the reduced argument, n in *np
+__device__ __forceinline__ double gl_reduce_fast(double x, int *np) {
+    const double r = x * gl_d(glibc_sincosf_tab, 4);
+    const int n = ((int)r + 0x800000) >> 24;
+    *np = n;
+    return __builtin_fma(-(double)n, gl_d(glibc_sincosf_tab, 5), x);
+}
+__device__ __forceinline__ double gl_reduce_large(uint32_t xi, int *np) {
+    const uint32_t *arr = &glibc_inv_pio4[(xi >> 26) & 15u];
+    const int shift = (int)((xi >> 23) & 7u);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(long long)res0 * gl_d(glibc_pi63, 0);
+}
+// s_cosf.c / s_sinf.c in one body: COS selects `n ^ 1` (cosf) or `n` (sinf) as sinf_poly's quadrant argument
+template <bool COS>
+__device__ __forceinline__ float gl_sincosf(float y) {
+    double x = (double)y;
+    const uint32_t top = gl_abstop12(y);
+    int n = 0, q = 0;                                                 // q: index into sign[] and the (n & 2) table select
+    if (top < 0x3f4u /* abstop12(pi/4) */) {
+        if (top < 0x398u /* abstop12(0x1p-12f) */) return COS ? 1.0f : y;
+    } else if (top < 0x42fu /* abstop12(120.0f) */) {
+        x = gl_reduce_fast(x, &n);
+        q = n;
+    } else if (top < 0x7f8u /* abstop12(inf) */) {
+        const uint32_t xi = __float_as_uint(y);
+        x = gl_reduce_large(xi, &n);
+        q = n + (int)(xi >> 31);
+    } else {
+        return gl_invalidf(y);
     }
-    return (float)v;
-}
-__device__ __noinline__ float shim_sinf(float x) {           // same reduction as shim_cosf; sin(x) = {s, c, -s, -c}[k & 3]
-    if (!(fabsf(x) <= 1048576.0f)) return x - x;
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    const double PIO2_1 = 1.57079632673412561417e+00;
-    const double PIO2_1T = 6.07710050650619224932e-11;
-    double xd = (double)x;
-    double kf = floor(xd * INV_PIO2 + 0.5);
-    double r = (xd - kf * PIO2_1) - kf * PIO2_1T;
-    long long k = (long long)kf;
-    double s = shim_ksin(r), c = shim_kcos(r);
-    double v;
-    switch (k & 3) {
-    case 0: v = s; break;
-    case 1: v = c; break;
-    case 2: v = -s; break;
-    default: v = -c; break;
+    const int sel = COS ? (n ^ 1) : n;                                // sinf_poly(x * s, x * x, p, sel)
+    const double x2 = x * x;
+    double r;
+    if ((sel & 1) == 0) {
+        const double s = ((q + 1) & 2) ? -1.0 : 1.0;                  // sign[q & 3] = {1, -1, -1, 1}
+        r = gl_sin_poly(x * s, x2);
+    } else {
+        r = gl_cos_poly(x2);
+        if (q & 2) r = -r;                                            // __sincosf_table[1]
     }
-    return (float)v;
+    return (float)r;
 }
-__device__ __forceinline__ double shim_log_reduce(double xd, double &e_out) {
-    const double SQRT2 = 1.41421356237309514547e+00;
-    uint64_t b = (uint64_t)__double_as_longlong(xd);
-    int e = (int)((b >> 52) & 0x7ff) - 1023;
-    double m = __longlong_as_double((long long)((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
-    if (m > SQRT2) { m = m * 0.5; e += 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double p = 4.34782608695652161754e-02;
-    p = 4.76190476190476164085e-02 + z * p;
-    p = 5.26315789473684181249e-02 + z * p;
-    p = 5.88235294117647050660e-02 + z * p;
-    p = 6.66666666666666657415e-02 + z * p;
-    p = 7.69230769230769273453e-02 + z * p;
-    p = 9.09090909090909116141e-02 + z * p;
-    p = 1.11111111111111104943e-01 + z * p;
-    p = 1.42857142857142849213e-01 + z * p;
-    p = 2.00000000000000011102e-01 + z * p;
-    p = 3.33333333333333314830e-01 + z * p;
-    p = 1.0 + z * p;
-    e_out = (double)e;
-    return (2.0 * s) * p;
+__device__ __forceinline__ float gl_cosf(float y) { return gl_sincosf<true>(y); }
+__device__ __forceinline__ float gl_sinf(float y) { return gl_sincosf<false>(y); }
+
+// e_logf.c.  `tab` = __logf_data.tab as 16 x {invc, logc}: the global table, or a copy the kernel staged in LDS.
+template <class TabPtr>
+__device__ __forceinline__ float gl_logf(float x, TabPtr tab) {
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2u == 0u) return -__builtin_inff();                  // __math_divzerof(1)
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return gl_invalidf(x);
+        ix = __float_as_uint(x * 8388608.0f);                         // subnormal: x * 0x1p23f
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const int k = (int)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = tab[2 * i], logc = tab[2 * i + 1];
+    const double z = (double)__uint_as_float(iz);
+    const double r = __builtin_fma(z, invc, -1.0);                                    // z*invc - 1
+    const double y0 = __builtin_fma((double)k, gl_d(glibc_logf_ln2, 0), logc);        // logc + k*Ln2
+    const double r2 = r * r;
+    double y = __builtin_fma(gl_d(glibc_logf_poly, 1), r, gl_d(glibc_logf_poly, 2));  // A1*r + A2
+    y = __builtin_fma(gl_d(glibc_logf_poly, 0), r2, y);                               // A0*r2 + y
+    y = __builtin_fma(y, r2, y0 + r);                                                 // y*r2 + (y0 + r)
+    return (float)y;
 }
-__device__ __noinline__ float shim_log10f(float x) {
-    if (x != x) return x;
-    if (x < 0.0f) return (x - x) / (x - x);
-    if (x == 0.0f) return -__builtin_inff();
-    if (x == __builtin_inff()) return x;
-    const double LOG10_2 = 3.01029995663981198017e-01;
-    const double INV_LN10 = 4.34294481903251816668e-01;
-    double e, lm = shim_log_reduce((double)x, e);
-    return (float)(e * LOG10_2 + lm * INV_LN10);
+// e_log10f.c (__ieee754_log10f): binary32 arithmetic, never fused (the file has no FMA variant)
+template <class TabPtr>
+__device__ __forceinline__ float gl_log10f(float x, TabPtr tab) {
+    const float two25 = 33554432.0f;
+    const float log10_2lo = __uint_as_float(glibc_log10f_consts[1]), ivln10 = __uint_as_float(glibc_log10f_consts[2]);
+    const float log10_2hi = __uint_as_float(glibc_log10f_consts[3]);
+    int hx = (int)__float_as_uint(x), k = 0;
+    if (hx < 0x00800000) {
+        if ((hx & 0x7fffffff) == 0) return -two25 / fabsf(x);         // log(+-0) = -inf
+        if (hx < 0) return (x - x) / (x - x);                         // log(-#) = NaN
+        k -= 25;
+        x *= two25;
+        hx = (int)__float_as_uint(x);
+    }
+    if (hx >= 0x7f800000) return x + x;
+    k += (hx >> 23) - 127;
+    const int i = (int)(((uint32_t)k & 0x80000000u) >> 31);
+    hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+    const float y = (float)(k + i);
+    x = __uint_as_float((uint32_t)hx);
+    const float z = y * log10_2lo + ivln10 * gl_logf(x, tab);
+    return z + y * log10_2hi;
 }
-__device__ __forceinline__ double shim_exp(double z) {
-    const double INV_LN2 = 1.44269504088896338700e+00;
-    const double LN2_HI = 6.93147180369123816490e-01;
-    const double LN2_LO = 1.90821492927058770002e-10;
-    double kf = floor(z * INV_LN2 + 0.5);
-    double r = (z - kf * LN2_HI) - kf * LN2_LO;
-    double p = 1.60590438368216133e-10;
-    p = 2.08767569878680989792e-09 + r * p;
-    p = 2.50521083854417187751e-08 + r * p;
-    p = 2.75573192239858906526e-07 + r * p;
-    p = 2.75573192239858906526e-06 + r * p;
-    p = 2.48015873015873015873e-05 + r * p;
-    p = 1.98412698412698412698e-04 + r * p;
-    p = 1.38888888888888894189e-03 + r * p;
-    p = 8.33333333333333321769e-03 + r * p;
-    p = 4.16666666666666643537e-02 + r * p;
-    p = 1.66666666666666657415e-01 + r * p;
-    p = 0.5 + r * p;
-    p = 1.0 + r * p;
-    p = 1.0 + r * p;
-    long long k = (long long)kf;
-    double scale = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
-    return p * scale;
+struct GlTabGlobal {                                                 // the table in global (constant) memory
+    __device__ __forceinline__ double operator[](uint32_t i) const { return gl_d(glibc_logf_tab, (int)i); }
+};
+
+// e_powf.c
+__device__ __forceinline__ double gl_pow_log2_inline(uint32_t ix) {
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int)top >> 23;
+    const double invc = gl_d(glibc_pow_log2_tab, 2 * (int)i), logc = gl_d(glibc_pow_log2_tab, 2 * (int)i + 1);
+    const double z = (double)__uint_as_float(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double y = __builtin_fma(gl_d(glibc_pow_log2_poly, 0), r, gl_d(glibc_pow_log2_poly, 1));
+    const double p = __builtin_fma(gl_d(glibc_pow_log2_poly, 2), r, gl_d(glibc_pow_log2_poly, 3));
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(gl_d(glibc_pow_log2_poly, 4), r, y0);
+    q = __builtin_fma(p, r2, q);
+    y = __builtin_fma(y, r4, q);
+    return y;
 }
-__device__ __noinline__ float shim_expf(float x) {
-    if (x != x) return x;
-    if (x > 100.0f) return __builtin_inff();
-    if (x < -110.0f) return 0.0f;
-    return (float)shim_exp((double)x);
+__device__ __forceinline__ float gl_exp2_inline(double xd, uint32_t sign_bias) {
+    const double SHIFT = gl_d(glibc_exp2f_shift_scaled, 0);
+    double kd = xd + SHIFT;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double r = xd - kd;
+    uint64_t t = glibc_exp2f_tab[ki & 31u];
+    const uint64_t ski = ki + sign_bias;
+    t += ski << 47;
+    const double s = __longlong_as_double((long long)t);
+    const double z = __builtin_fma(gl_d(glibc_exp2f_poly, 0), r, gl_d(glibc_exp2f_poly, 1));
+    const double r2 = r * r;
+    double y = __builtin_fma(gl_d(glibc_exp2f_poly, 2), r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
 }
-__device__ __noinline__ float shim_powf(float x, float y) {
+__device__ __forceinline__ int gl_checkint(uint32_t iy) {             // 0: not an integer, 1: odd, 2: even
+    const int e = (int)(iy >> 23 & 0xffu);
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+    if (iy & (1u << (0x7f + 23 - e))) return 1;
+    return 2;
+}
+__device__ __forceinline__ bool gl_zeroinfnan(uint32_t ix) { return 2u * ix - 1u >= 2u * 0x7f800000u - 1u; }
+__device__ __forceinline__ bool gl_issignalingf(float x) { return 2u * (__float_as_uint(x) ^ 0x00400000u) > 2u * 0x7fc00000u; }
+__device__ __forceinline__ float gl_xflowf(uint32_t sign, float y) { return (sign ? -y : y) * y; }   // math_errf.c
+__device__ __noinline__ float gl_powf(float x, float y) {
     const float INF = __builtin_inff();
-    if (y == 0.0f || x == 1.0f) return 1.0f;
-    if (x != x || y != y) return x + y;
-    if (x < 0.0f) return (x - x) / (x - x);
-    if (x == 0.0f) return y > 0.0f ? 0.0f : INF;
-    if (x == INF) return y > 0.0f ? INF : 0.0f;
-    if (y == INF) return x > 1.0f ? INF : 0.0f;
-    if (y == -INF) return x > 1.0f ? 0.0f : INF;
-    const double LN2 = 6.93147180559945286227e-01;
-    double e, lm = shim_log_reduce((double)x, e);
-    double z = (double)y * (e * LN2 + lm);
-    if (z > 100.0) return INF;
-    if (z < -110.0) return 0.0f;
-    return (float)shim_exp(z);
+    uint32_t sign_bias = 0;
+    uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || gl_zeroinfnan(iy)) {
+        if (gl_zeroinfnan(iy)) {
+            if (2u * iy == 0u) return gl_issignalingf(x) ? x + y : 1.0f;
+            if (ix == 0x3f800000u) return gl_issignalingf(y) ? x + y : 1.0f;
+            if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+            if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+            if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+            return y * y;
+        }
+        if (gl_zeroinfnan(ix)) {
+            float x2 = x * x;
+            if ((ix & 0x80000000u) && gl_checkint(iy) == 1) { x2 = -x2; sign_bias = 1; }
+            if (2u * ix == 0u && (iy & 0x80000000u)) return sign_bias ? -INF : INF;   // __math_divzerof
+            return (iy & 0x80000000u) ? 1.0f / x2 : x2;
+        }
+        if (ix & 0x80000000u) {
+            const int yint = gl_checkint(iy);
+            if (yint == 0) return gl_invalidf(x);
+            if (yint == 1) sign_bias = 1u << 16;                      // SIGN_BIAS
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {
+            ix = __float_as_uint(x * 8388608.0f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    const double logx = gl_pow_log2_inline(ix);
+    const double ylogx = (double)y * logx;
+    if ((((uint64_t)__double_as_longlong(ylogx) >> 47) & 0xffffu) >= 0x80bfu /* asuint64(126.0) >> 47 */) {
+        if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -INF : INF;              // __math_oflowf
+        if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;                         // __math_uflowf
+        if (ylogx < -149.0) return gl_xflowf(sign_bias, 0x1.4p-75f);                  // __math_may_uflowf
+    }
+    return gl_exp2_inline(ylogx, sign_bias);
+}
+// e_expf.c
+__device__ __noinline__ float gl_expf(float x) {
+    const double xd = (double)x;
+    const uint32_t abstop = gl_abstop12(x);
+    if (abstop >= 0x42bu /* abstop12(88.0f) */) {
+        if (__float_as_uint(x) == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_inff();
+        if (x < -0x1.9fe368p6f) return 0.0f;
+        if (x < -0x1.9d1d9ep6f) return gl_xflowf(0, 0x1.4p-75f);
+    }
+    const double InvLn2N = gl_d(glibc_exp2f_invln2_scaled, 0), SHIFT = gl_d(glibc_exp2f_shift, 0);
+    double kd = __builtin_fma(InvLn2N, xd, SHIFT);                    // z + SHIFT, z = InvLn2N*xd (fused in the binary)
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double r = __builtin_fma(InvLn2N, xd, -kd);                 // z - kd (vfmsub)
+    uint64_t t = glibc_exp2f_tab[ki & 31u];
+    t += ki << 47;
+    const double s = __longlong_as_double((long long)t);
+    const double z = __builtin_fma(gl_d(glibc_exp2f_poly_scaled, 0), r, gl_d(glibc_exp2f_poly_scaled, 1));
+    const double r2 = r * r;
+    double y = __builtin_fma(gl_d(glibc_exp2f_poly_scaled, 2), r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
 }
 
 // math.rs:15-19 (log10, not ln: SURVEY T3)
-__device__ __forceinline__ float rand_f32_nd(uint32_t &s) {
+template <class TabPtr>
+__device__ __forceinline__ float rand_f32_nd(uint32_t &s, TabPtr logtab) {
     float theta = 6.283185f * rand_f32(s);
-    float rho = __builtin_sqrtf(-2.0f * shim_log10f(rand_f32(s)));
-    return rho * shim_cosf(theta);
+    float rho = __builtin_sqrtf(-2.0f * gl_log10f(rand_f32(s), logtab));
+    return rho * gl_cosf(theta);
 }
 // vec3.rs:66-68 -- x, y, z drawn in that order
-__device__ __forceinline__ V3 rand_in_unit_sphere(uint32_t &s) {
-    float x = rand_f32_nd(s);
-    float y = rand_f32_nd(s);
-    float z = rand_f32_nd(s);
+template <class TabPtr>
+__device__ __forceinline__ V3 rand_in_unit_sphere(uint32_t &s, TabPtr logtab) {
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+#pragma nounroll
+    for (int k = 0; k < 3; k++) { x = y; y = z; z = rand_f32_nd(s, logtab); }   // one copy of the code, three draws in order
     return normalized(mk(x, y, z));
 }
 
 // vec3.rs:80-90 (+ mix :197-205) and :262-270, one channel
 __device__ __forceinline__ uint32_t srgb_quantize(float c) {
     float cutoff = (c < 0.0031308f) ? 1.0f : 0.0f;
-    float higher = 1.055f * shim_powf(c, 1.0f / 2.4f) - 0.055f;
+    float higher = 1.055f * gl_powf(c, 1.0f / 2.4f) - 0.055f;
     float lower = c * 12.92f;
     float s = (higher * (1.0f - cutoff)) + lower * cutoff;
     float q = floorf(s * 255.0f);
     if (q < 0.0f) q = 0.0f;
     if (q > 255.0f) q = 255.0f;
     return (q != q) ? 0u : (uint32_t)q;          // Rust `as u8`: NaN -> 0
+}
+
+// ---- exact division with a per-ray reciprocal -------------------------------------------------------------
+// The slab test divides by the ray direction 12 times per inner step (ray.rs:70-71) and bit-exactness forbids
+// `x * (1/d)`.  hipcc's IEEE expansion is 11 instructions per quotient (2 div_scale, rcp, 2 reciprocal-refinement
+// FMAs, mul, 3 residual FMAs, div_fmas, div_fixup).  Everything that depends only on d is hoisted to once per ray:
+// r = RN(1/d); per quotient the same quotient refinement the hardware sequence ends with remains --
+//   q0 = a*r; q1 = q0 + (a - q0*d)*r; q2 = q1 + (a - q1*d)*r      (residuals exact in FMA)
+// q1 is faithful, q2 = RN(a/d) (Markstein's theorem) -- PROVIDED nothing under/overflows.  That is guaranteed when
+// |d| in [2^-60, 2], |o| <= 2^40 (checked once per ray; scene bounds <= 2^40 are checked at upload) and
+// |q| > 2^-40 (checked on the results, see slab_pair): then 2^-100 <= |a| <= 2^41, so every residual is representable.  Lanes failing the check (a == 0: origin exactly on a
+// bounding plane; axis-parallel rays; inf/NaN) redo the step with IEEE divisions.  The probe op 14 and
+// tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
+__device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
+    const float q0 = a * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
+}
+// u8 -> f32 / 255.0 (vec3.rs:252-260) with the same exact two-correction quotient as fdiv_ray: the numerator is an
+// integer in [0, 255] and the divisor the constant 255, so no range guard is needed (0 gives 0 exactly);
+// tests/test_gpu_more.py checks all 256 values against IEEE division.
+__device__ __forceinline__ float u8_over_255(uint32_t k) {
+    return fdiv_ray((float)k, 255.0f, 0.0039215688593685627f /* RN(1/255) */);
 }
 
 } // namespace mipt

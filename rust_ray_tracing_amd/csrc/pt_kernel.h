@@ -97,7 +97,5 @@ hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float d
 
 hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, float divisor, uint16_t *rgba16,
                               hipStream_t stream);
-hipError_t launch_debug_eval(int op, const float *a, const float *b, unsigned long long n, float *out,
-                             hipStream_t stream);
 
 } // namespace mipt

@@ -55,22 +55,6 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; 
 __device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float min3_abs(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// ---- exact division with a per-ray reciprocal -------------------------------------------------------------
-// The slab test divides by the ray direction 12 times per inner step (ray.rs:70-71) and bit-exactness forbids
-// `x * (1/d)`.  hipcc's IEEE expansion is 11 instructions per quotient (2 div_scale, rcp, 2 reciprocal-refinement
-// FMAs, mul, 3 residual FMAs, div_fmas, div_fixup).  Everything that depends only on d is hoisted to once per ray:
-// r = RN(1/d); per quotient the same quotient refinement the hardware sequence ends with remains --
-//   q0 = a*r; q1 = q0 + (a - q0*d)*r; q2 = q1 + (a - q1*d)*r      (residuals exact in FMA)
-// q1 is faithful, q2 = RN(a/d) (Markstein's theorem) -- PROVIDED nothing under/overflows.  That is guaranteed when
-// |d| in [2^-60, 2], |o| <= 2^40 (checked once per ray; scene bounds <= 2^40 are checked at upload) and
-// |q| > 2^-40 (checked on the results, see slab_pair): then 2^-100 <= |a| <= 2^41, so every residual is representable.  Lanes failing the check (a == 0: origin exactly on a
-// bounding plane; axis-parallel rays; inf/NaN) redo the step with IEEE divisions.  The probe op 14 and
-// tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
-__device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
-    const float q0 = a * r;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
-    return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
-}
 // Per-ray guard: every |d_i| in [2^-60, 2] and every |o_i| <= 2^40.  mipt_scene_create rejects scenes whose bounds
 // exceed 2^40, so |a| = |b - o| <= 2^41 and |q| = |a/d| <= 2^101 < 2^104: no overflow anywhere in fdiv_ray, and no
 // NaN can appear (all operands finite, d != 0).  What is left to check per step is the small side (slab_pair).
@@ -127,13 +111,6 @@ __device__ __forceinline__ void slab_pair(V3 o, V3 d, V3 rd, bool safe, float4 r
     }
 }
 
-// u8 -> f32 / 255.0 (vec3.rs:252-260) with the same exact two-correction quotient as fdiv_ray: the numerator is an
-// integer in [0, 255] and the divisor the constant 255, so no range guard is needed (0 gives 0 exactly);
-// tests/test_gpu_more.py checks all 256 values against IEEE division.
-__device__ __forceinline__ float u8_over_255(uint32_t k) {
-    return fdiv_ray((float)k, 255.0f, 0.0039215688593685627f /* RN(1/255) */);
-}
-
 // texture.rs:33-38; out-of-range indices (reference: panic) are clamped and counted
 __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uint32_t width, uint32_t height, float u, float v, DevStats *st) {
     float fu = u - truncf(u), fv = v - truncf(v);                  // f32::fract
@@ -153,7 +130,7 @@ __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uin
 
 // ---------------------------------------------------------------------------------------------------------------
 // Shading mode 1: the wgpu backend's material model (rt_compute.wgsl:126-294, 503-569), restated operator for operator
-// exactly as the CPU oracle restates it (one rounded f32 op per WGSL operator, transcendentals through the shim, exact
+// exactly as the CPU oracle restates it (one rounded f32 op per WGSL operator, transcendentals through the glibc restatement, exact
 // f32 bilinear weights).  SURVEY 8(f) rank 2.  Returns true when the path ends (`break` in the WGSL loop).
 // ---------------------------------------------------------------------------------------------------------------
 struct V4 { float x, y, z, w; };
@@ -202,8 +179,8 @@ __device__ __forceinline__ V3 sample_ggx_vndf(V3 ve, float ax, float ay, uint32_
     const V3 T2 = cross(Vh, T1);
     const float r = __builtin_sqrtf(u1);
     const float phi = 2.0f * 3.1415926535f * u2;
-    const float t1 = r * shim_cosf(phi);
-    float t2 = r * shim_sinf(phi);
+    const float t1 = r * gl_cosf(phi);
+    float t2 = r * gl_sinf(phi);
     const float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * __builtin_sqrtf(1.0f - t1 * t1) + s * t2;
     const float k = __builtin_sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
@@ -219,7 +196,7 @@ __device__ __forceinline__ V3 cosine_sample_hemisphere(uint32_t &rng) {         
         float theta, r;
         if (fabsf(ox) > fabsf(oy)) { r = ox; theta = 0.7853981634f * (oy / ox); }
         else { r = oy; theta = 1.5707963268f - 0.7853981634f * (ox / oy); }
-        dx = r * shim_cosf(theta); dy = r * shim_sinf(theta);
+        dx = r * gl_cosf(theta); dy = r * gl_sinf(theta);
     }
     const float z = __builtin_sqrtf(fmaxf(0.0f, 1.0f - dx * dx - dy * dy));
     return mk(dx, dy, z);
@@ -245,14 +222,14 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
     if (front_face) ior = 1.0f / ior;                                                  // set_surface_properties, :251-294
     if (m.tex[0][1] != 0u) {
         const V4 tx = sample_texture_bilinear(sc.texels, m.tex[0][0], m.tex[0][1], m.tex[0][2], uvx, uvy); n_tex++;
-        base = mk(shim_powf(tx.x, 2.2f), shim_powf(tx.y, 2.2f), shim_powf(tx.z, 2.2f));
+        base = mk(gl_powf(tx.x, 2.2f), gl_powf(tx.y, 2.2f), gl_powf(tx.z, 2.2f));
     }
     if (m.tex[1][1] != 0u) { transparency = sample_texture_bilinear(sc.texels, m.tex[1][0], m.tex[1][1], m.tex[1][2], uvx, uvy).w; n_tex++; }
     if (m.tex[2][1] != 0u) { roughness = sample_texture_bilinear(sc.texels, m.tex[2][0], m.tex[2][1], m.tex[2][2], uvx, uvy).y; n_tex++; }
     if (m.tex[3][1] != 0u) { metallic = sample_texture_bilinear(sc.texels, m.tex[3][0], m.tex[3][1], m.tex[3][2], uvx, uvy).z; n_tex++; }
     if (m.tex[4][1] != 0u) {
         const V4 tx = sample_texture_bilinear(sc.texels, m.tex[4][0], m.tex[4][1], m.tex[4][2], uvx, uvy); n_tex++;
-        emission = mk(shim_powf(tx.x, 2.2f), shim_powf(tx.y, 2.2f), shim_powf(tx.z, 2.2f));
+        emission = mk(gl_powf(tx.x, 2.2f), gl_powf(tx.y, 2.2f), gl_powf(tx.z, 2.2f));
     }
     V3 tangent, bitangent;
     build_onb(normal, tangent, bitangent);
@@ -305,8 +282,8 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
             if (dot(new_dir, normal) > 0.0f) return true;
             V3 absorption = mk(1.0f, 1.0f, 1.0f);
             if (!front_face)
-                absorption = mk(shim_expf(-(1.0f - base.x) * transmitted_distance), shim_expf(-(1.0f - base.y) * transmitted_distance),
-                                shim_expf(-(1.0f - base.z) * transmitted_distance));
+                absorption = mk(gl_expf(-(1.0f - base.x) * transmitted_distance), gl_expf(-(1.0f - base.y) * transmitted_distance),
+                                gl_expf(-(1.0f - base.z) * transmitted_distance));
             ray_color = ray_color * absorption;
         } else {
             new_dir = diffuse_dir;
@@ -331,12 +308,15 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
 } // namespace
 
 #ifndef MIPT_MIN_WAVES_PER_SIMD
-#define MIPT_MIN_WAVES_PER_SIMD 1
+#define MIPT_MIN_WAVES_PER_SIMD 5      // CPU-backend shading: 96 VGPRs, no scratch (97 without the bound = 4 waves)
 #endif
 template <bool COUNT, bool CULL, bool LDS_TOP, int SHADING>
-__global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_trace_kernel(DevScene sc, DevParams pr) {
+__global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SIMD : 1) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];   // row kStackLds: scratch target of the branch-free push
     __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
+    __shared__ double s_logtab[32];                                    // __logf_data.tab (16 x {invc, logc}) for gl_log10f
+    if (threadIdx.x < 32u) s_logtab[threadIdx.x] = gl_d(glibc_logf_tab, (int)threadIdx.x);
+    __syncthreads();
     if (LDS_TOP) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)kTopPairs * 4u; i += kBlockThreads) s_top[i] = sc.top[i];
         __syncthreads();
@@ -414,7 +394,7 @@ __global__ __launch_bounds__(kBlockThreads, MIPT_MIN_WAVES_PER_SIMD) void pt_tra
                         emitted = emitted + mk(m.emis[0], m.emis[1], m.emis[2]);
                     }
                     incoming = incoming + emitted * ray_color;                       // ray.rs:177
-                    const V3 new_dir = normalized(normal + rand_in_unit_sphere(rng)); // ray.rs:179-180
+                    const V3 new_dir = normalized(normal + rand_in_unit_sphere(rng, (const double *)s_logtab)); // ray.rs:179-180
                     o = point + new_dir * 0.0001f;                                   // ray.rs:181
                     d = new_dir;
                     bounces += 1;
@@ -676,47 +656,12 @@ __global__ void tonemap_kernel(const float *__restrict__ hdr, unsigned long long
     }
 }
 
-// ---- device-arithmetic probe (diagnostic entry mipt_debug_eval; used by the GPU known-answer tests) ----
-__global__ void debug_eval_kernel(int op, const float *__restrict__ a, const float *__restrict__ b, unsigned long long n,
-                                  float *__restrict__ out) {
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
-        const float x = a[i], y = b ? b[i] : 0.0f;
-        float r = 0.0f;
-        switch (op) {
-        case 0: r = shim_cosf(x); break;
-        case 1: r = shim_log10f(x); break;
-        case 2: r = shim_powf(x, y); break;
-        case 3: r = x / y; break;
-        case 4: r = __builtin_sqrtf(x); break;
-        case 5: r = x * y; break;
-        case 6: r = x + y; break;
-        case 7: r = fminf(x, y); break;
-        case 8: r = fmaxf(x, y); break;
-        case 9: { uint32_t s = __float_as_uint(x); r = rand_f32(s); } break;             // xorshift + u32->f32 + /2^32
-        case 10: { uint32_t s = __float_as_uint(x); r = rand_f32_nd(s); } break;
-        case 11: { uint32_t s = __float_as_uint(x); V3 v = rand_in_unit_sphere(s); r = (y == 0.0f) ? v.x : (y == 1.0f ? v.y : v.z); } break;
-        case 12: r = __uint_as_float(srgb_quantize(x)); break;
-        case 13: r = x - truncf(x); break;
-        case 14: r = fdiv_ray(x, y, 1.0f / y); break;
-        case 15: r = u8_over_255(__float_as_uint(x)); break;                                          // exact-division helper (valid range only)
-        default: break;
-        }
-        out[i] = r;
-    }
-}
-
-hipError_t launch_debug_eval(int op, const float *a, const float *b, unsigned long long n, float *out, hipStream_t stream) {
-    hipLaunchKernelGGL(debug_eval_kernel, dim3(1024), dim3(256), 0, stream, op, a, b, n, out);
-    return hipGetLastError();
-}
-
 // ---- pp_compute.wgsl:7-34: linear_to_srgb, THEN aces_filmic, stored as rgba16unorm -------------------------------
 // One rounded f32 operation per WGSL operator (WGSL leaves FMA fusion to the implementation: unpinned); pow through
-// the same shim as the sRGB epilogue; unorm16 = floor(x * 65535 + 0.5).
+// the same powf as the sRGB epilogue; unorm16 = floor(x * 65535 + 0.5).
 __device__ __forceinline__ float pp_channel(float c) {
     const float cutoff = (c < 0.0031308f) ? 1.0f : 0.0f;
-    const float higher = 1.055f * shim_powf(c, 1.0f / 2.4f) - 0.055f;
+    const float higher = 1.055f * gl_powf(c, 1.0f / 2.4f) - 0.055f;
     const float lower = c * 12.92f;
     const float x = (higher * (1.0f - cutoff)) + lower * cutoff;          // mix(higher, lower, cutoff)
     const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
@@ -754,17 +699,23 @@ static int occ_t() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, TOP, SHADING>, kBlockThreads, 0) != hipSuccess) n = 1;
     return n;
 }
-// instantiations: CPU-backend shading x {count, cull, lds_top}; wgpu-shader shading x {count, cull}
+// instantiations: CPU-backend shading x {count, cull} (x lds_top in a TUNING build); wgpu-shader shading x {count, cull}
+#ifdef MIPT_TUNING
+#define MIPT_DISPATCH_TOP(FN, ...)                                                                                      \
+        if (top) {                                                                                                      \
+            if (count) return cull ? FN<true, true, true, 0>(__VA_ARGS__) : FN<true, false, true, 0>(__VA_ARGS__);      \
+            return cull ? FN<false, true, true, 0>(__VA_ARGS__) : FN<false, false, true, 0>(__VA_ARGS__);               \
+        }
+#else
+#define MIPT_DISPATCH_TOP(FN, ...) (void)top;
+#endif
 #define MIPT_DISPATCH(FN, ...)                                                                                          \
     do {                                                                                                                \
         if (shading == 1) {                                                                                             \
             if (count) return cull ? FN<true, true, false, 1>(__VA_ARGS__) : FN<true, false, false, 1>(__VA_ARGS__);    \
             return cull ? FN<false, true, false, 1>(__VA_ARGS__) : FN<false, false, false, 1>(__VA_ARGS__);             \
         }                                                                                                               \
-        if (top) {                                                                                                      \
-            if (count) return cull ? FN<true, true, true, 0>(__VA_ARGS__) : FN<true, false, true, 0>(__VA_ARGS__);      \
-            return cull ? FN<false, true, true, 0>(__VA_ARGS__) : FN<false, false, true, 0>(__VA_ARGS__);               \
-        }                                                                                                               \
+        MIPT_DISPATCH_TOP(FN, __VA_ARGS__)                                                                              \
         if (count) return cull ? FN<true, true, false, 0>(__VA_ARGS__) : FN<true, false, false, 0>(__VA_ARGS__);        \
         return cull ? FN<false, true, false, 0>(__VA_ARGS__) : FN<false, false, false, 0>(__VA_ARGS__);                 \
     } while (0)

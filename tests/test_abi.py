@@ -9,8 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "mipt.h")).read()
+def header_symbols(name="mipt.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mipt_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,6 +24,23 @@ def test_every_declared_symbol_is_exported(rrt):
         assert hasattr(lib, s), f"{s} declared in include/mipt.h but not exported by libmipt.so"
     assert sorted(L.EXPORTS) == syms, "binding list and header disagree"
     assert lib.mipt_abi_version() == 1
+
+
+def test_diag_probe_is_a_separate_library(rrt):
+    """The device-arithmetic probe (include/mipt_diag.h) lives in libmipt_diag.so; the product exports none of it."""
+    import subprocess
+    from rust_ray_tracing_amd import _lib as L
+    diag = rrt.load_diag()
+    syms = header_symbols("mipt_diag.h")
+    assert sorted(L.DIAG_EXPORTS) == syms
+    for s in syms:
+        assert hasattr(diag, s)
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "debug_eval" not in out and "mipt_diag" not in out
+    # and the product reads no tuning knob from the environment (those exist only in a `make TUNING=1` build)
+    strings = subprocess.run(["strings", L.LIB_PATH], capture_output=True, text=True).stdout
+    for knob in ("MIPT_LDS_TOP", "MIPT_REVERSE_TILES", "MIPT_SERVICE_NUM", "MIPT_SERVICE_DEN", "MIPT_BLOCKS_PER_CU"):
+        assert knob not in strings, knob
 
 
 def test_no_oracle_or_cpu_fallback_linked(rrt):

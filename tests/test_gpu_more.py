@@ -146,7 +146,7 @@ def test_device_arithmetic_matches_oracle(rrt, orc):
         a = np.ascontiguousarray(a, dtype=np.float32)
         out = np.zeros_like(a)
         bb = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
-        assert lib.mipt_debug_eval(op, a.ctypes.data, None if bb is None else bb.ctypes.data, a.size, out.ctypes.data) == 0
+        assert rrt.load_diag().mipt_debug_eval(op, a.ctypes.data, None if bb is None else bb.ctypes.data, a.size, out.ctypes.data) == 0
         return out
 
     def same(x, y):
@@ -162,11 +162,11 @@ def test_device_arithmetic_matches_oracle(rrt, orc):
         assert same(dev(4, np.abs(a)), np.sqrt(np.abs(a)))     # correctly rounded sqrt (vec3.rs:95)
         assert same(dev(5, a, b), a * b) and same(dev(6, a, b), a + b)   # denormals preserved, no FMA
     x = np.concatenate([(rng.random(50000) * 6.2832).astype(np.float32), np.float32([0, 6.283185, 3.1415927, 1.5707964, np.inf, np.nan])])
-    assert same(dev(0, x), np.array([O.orc_shim_cosf(float(v)) for v in x], dtype=np.float32))
+    assert same(dev(0, x), np.array([O.orc_glibc_cosf(float(v)) for v in x], dtype=np.float32))
     r = np.concatenate([rng.random(50000).astype(np.float32), np.float32([0, 1, 1e-45, 2.3e-10, np.inf, -1])])
-    assert same(dev(1, r), np.array([O.orc_shim_log10f(float(v)) for v in r], dtype=np.float32))
+    assert same(dev(1, r), np.array([O.orc_glibc_log10f(float(v)) for v in r], dtype=np.float32))
     y = np.full(len(r), np.float32(1) / np.float32(2.4), dtype=np.float32)
-    assert same(dev(2, r, y), np.array([O.orc_shim_powf(float(v), float(y[0])) for v in r], dtype=np.float32))
+    assert same(dev(2, r, y), np.array([O.orc_glibc_powf(float(v), float(y[0])) for v in r], dtype=np.float32))
     seeds = rng.integers(1, 2**32, 30000, dtype=np.uint32)
     want = np.zeros((len(seeds), 3), dtype=np.float32)
     for i, sd in enumerate(seeds):
@@ -294,7 +294,7 @@ def test_fast_division_is_ieee(rrt):
 
     def dev(op, a, b):
         out = np.zeros_like(a)
-        assert lib.mipt_debug_eval(op, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data) == 0
+        assert rrt.load_diag().mipt_debug_eval(op, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data) == 0
         return out
     rng = np.random.default_rng(11)
     n = 4_000_000
@@ -322,7 +322,7 @@ def test_u8_over_255_is_ieee(rrt):
     """Texel unpack (vec3.rs:252-260): the kernel's 5-instruction quotient must equal (k as f32) / 255.0 for all 256 bytes."""
     k = np.arange(256, dtype=np.uint32)
     out = np.zeros(256, dtype=np.float32)
-    assert rrt.load().mipt_debug_eval(15, k.view(np.float32).ctypes.data, None, 256, out.ctypes.data) == 0
+    assert rrt.load_diag().mipt_debug_eval(15, k.view(np.float32).ctypes.data, None, 256, out.ctypes.data) == 0
     want = k.astype(np.float32) / np.float32(255.0)
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
 

@@ -96,7 +96,7 @@ def test_rand_nd_uses_log10_and_draw_order(orc):  # math.rs:15-19
     theta = np.float32(6.283185) * r1                      # first draw -> theta
     rho = np.sqrt(np.float32(-2.0) * np.float32(math.log10(float(r2))))  # second draw -> rho, log10
     want = float(rho) * math.cos(float(theta))
-    got = O.orc_rand_f32_nd(C.byref(st), orc.LIBM_SHIM)
+    got = O.orc_rand_f32_nd(C.byref(st), orc.LIBM_GLIBC235)
     assert abs(got - want) <= 2e-7 * max(1.0, abs(want))
     assert st.value == x2                                  # exactly two draws
 
@@ -242,7 +242,7 @@ def test_srgb_quantise(orc):  # vec3.rs:80-90, 262-270
 
     def q(v):
         srgb = F3()
-        O.orc_linear_to_srgb(C.byref(F3(v, v, v)), orc.LIBM_SHIM, C.byref(srgb))
+        O.orc_linear_to_srgb(C.byref(F3(v, v, v)), orc.LIBM_GLIBC235, C.byref(srgb))
         out = (C.c_uint8 * 3)()
         O.orc_quantize(C.byref(srgb), C.byref(out))
         return out[0], srgb[0]
@@ -276,42 +276,7 @@ def test_texture_color_at(orc):  # texture.rs:33-38
     assert list(out) == list(px[1, 2])
 
 
-# ---- the transcendental shim vs the platform libm (what the Rust binary would call) ----
-def test_shim_close_to_libm(orc):
-    O = orc.load()
-    rng = np.random.default_rng(5)
-    x = (rng.random(20000) * 6.283185).astype(np.float32)
-    got = np.array([O.orc_shim_cosf(float(v)) for v in x], dtype=np.float32)
-    ref = np.cos(x.astype(np.float64))
-    assert np.all(got == ref.astype(np.float32))                        # correctly rounded on this sample
-    r = rng.random(20000).astype(np.float32)
-    got = np.array([O.orc_shim_log10f(float(v)) for v in r], dtype=np.float32)
-    assert np.all(got == np.log10(r.astype(np.float64)).astype(np.float32))
-    y = np.float32(1.0) / np.float32(2.4)
-    got = np.array([O.orc_shim_powf(float(v), float(y)) for v in r], dtype=np.float32)
-    assert np.all(got == np.power(r.astype(np.float64), np.float64(y)).astype(np.float32))
-    # special values
-    assert O.orc_shim_log10f(0.0) == -math.inf and O.orc_shim_log10f(1.0) == 0.0
-    assert math.isnan(O.orc_shim_log10f(-1.0)) and math.isnan(O.orc_shim_cosf(math.inf))
-    assert O.orc_shim_powf(0.0, float(y)) == 0.0 and O.orc_shim_powf(1.0, 5.0) == 1.0 and O.orc_shim_cosf(0.0) == 1.0
-
-
-def test_libm_sensitivity_is_small(orc):
-    """Oracle with the deterministic shim vs oracle calling glibc cosf/log10f/powf: the only place the
-    restatement can differ from the real Rust binary.  The difference must stay at the
-    'a few paths flip' level; the measured RMSE is printed for DESIGN.md."""
-    from rust_ray_tracing_amd import synth
-    tris, mats, texs, cam = synth.make_scene("atrium", n_target=20000, tex_size=32)
-    t, nodes = orc.bvh_build(tris)
-    m = np.array(list(mats.values()))
-    camera = orc.camera_from_pose(*cam)
-    a, ra, _ = orc.render(t, nodes, m, texs, camera, 96, 54, 8, 16, libm=orc.LIBM_SHIM)
-    b, rb, _ = orc.render(t, nodes, m, texs, camera, 96, 54, 8, 16, libm=orc.LIBM_HOST)
-    rmse = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
-    frac = float(np.mean((a != b).any(axis=2)))
-    print(f"shim-vs-glibc: rmse={rmse:.3e}, pixels differing={frac:.3%}, mean={a.mean():.4f}")
-    assert rmse < 0.05 and abs(float(a.mean()) - float(b.mean())) < 5e-3
-    assert np.mean(np.abs(ra.astype(int) - rb.astype(int)) > 8) < 0.05
+# (the transcendentals -- cosf / log10f / powf -- are pinned against the platform libm in tests/test_libm_pin.py)
 
 
 # ---- B10: struct layout ----

@@ -34,24 +34,24 @@ def test_radiance_and_counters_agree_bit_for_bit(rrt, orc, kind, kw, w, h, spp, 
     assert cnt["rays"] > len(pixels) * spp                                 # bounces happened
 
 
-def test_transcendental_shim_restated_in_python_matches_c(orc):
+def test_python_reading_on_the_host_libm_matches_the_c_restatement(orc):
     from oracle import pt_oracle_py as py
     import ctypes as C
     lib = orc.load()
-    lib.orc_shim_cosf.restype = C.c_float; lib.orc_shim_cosf.argtypes = [C.c_float]
-    lib.orc_shim_log10f.restype = C.c_float; lib.orc_shim_log10f.argtypes = [C.c_float]
+    lib.orc_glibc_cosf.restype = C.c_float; lib.orc_glibc_cosf.argtypes = [C.c_float]
+    lib.orc_glibc_log10f.restype = C.c_float; lib.orc_glibc_log10f.argtypes = [C.c_float]
     rng = np.random.default_rng(4)
     xs = np.concatenate([rng.uniform(0, 6.2832, 3000), rng.uniform(-50, 50, 500), [0.0, 1.5707964, 3.1415927, 6.283185]]).astype(np.float32)
     for x in xs:
-        assert np.float32(lib.orc_shim_cosf(float(x))).view(np.uint32) == py.shim_cosf(x).view(np.uint32), x
+        assert np.float32(lib.orc_glibc_cosf(float(x))).view(np.uint32) == py.libm_cosf(x).view(np.uint32), x
     us = np.concatenate([rng.uniform(0, 1, 3000), rng.uniform(0, 1e-6, 200), [1.0, 0.5, 2.3283064e-10]]).astype(np.float32)
     for u in us:
-        assert np.float32(lib.orc_shim_log10f(float(u))).view(np.uint32) == py.shim_log10f(u).view(np.uint32), u
+        assert np.float32(lib.orc_glibc_log10f(float(u))).view(np.uint32) == py.libm_log10f(u).view(np.uint32), u
     seeds = rng.integers(1, 2**32, 300)
     lib.orc_rand_in_unit_sphere.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float * 3)]
     for s in seeds:
         st = C.c_uint32(int(s)); out = (C.c_float * 3)()
-        lib.orc_rand_in_unit_sphere(C.byref(st), orc.LIBM_SHIM, C.byref(out))
+        lib.orc_rand_in_unit_sphere(C.byref(st), orc.LIBM_GLIBC235, C.byref(out))
         ps = [int(s)]
         v = py.rand_in_unit_sphere(ps)
         assert ps[0] == st.value
