@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 1
+#define MIPT_ABI_VERSION 2
 
 /* ---- PODs, byte-identical to the reference's #[repr(C, align(16))] structs ---------- */
 typedef struct { float x, y, z; } MiptVec3;                 /* src/math/vec3.rs:55-59  (12 B) */
@@ -146,7 +146,8 @@ enum MiptStatus {
     MIPT_ERR_SCENE_LIMIT   = -3,  /* scene exceeds device-format limits */
     MIPT_ERR_BVH           = -4,  /* malformed BVH handed to mipt_scene_create */
     MIPT_ERR_IO            = -5,  /* file not found / parse error (OBJ loader) */
-    MIPT_ERR_STACK         = -6   /* traversal stack overflowed during render (result incomplete) */
+    MIPT_ERR_STACK         = -6,  /* traversal stack overflowed during render (result incomplete) */
+    MIPT_ERR_RCCL          = -7   /* RCCL communicator / collective error (mipt_render_multi) */
 };
 
 /* ---- the seam ----------------------------------------------------------------------- */
@@ -187,6 +188,43 @@ int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor
  * rgba16unorm), linear_to_srgb, THEN aces_filmic, written as RGBA16 unorm (4 x u16 per pixel, alpha 65535) -- the pixel
  * format Renderer::render saves (renderer.rs:67-73, ColorType::Rgba16).  The CPU backend's epilogue is mipt_tonemap_device. */
 int mipt_postprocess_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint16_t *d_rgba16, void *hip_stream);
+
+/* ---- all GPUs of one node behind one call --------------------------------------------- */
+
+/* The reference's host is a single process with one Rc<RefCell<Scene>> (src/main.rs:46) and a blocking
+ * `match backend` arm (src/renderer.rs:57-63), so its multi-GPU arm must be one call from one thread.
+ * A MiptMulti holds a scene replica, a HIP stream and an RCCL communicator (ncclCommInitAll) per device. */
+typedef struct MiptMulti MiptMulti;
+
+enum MiptMultiMode {
+    MIPT_MULTI_TILES   = 0,  /* 8x8 image tiles round-robin over the devices (pixel seeds, cpu.rs:28-29, make the frame
+                              * bit-identical to the single-GPU frame); ONE ncclGather of rank-packed f32 slices to
+                              * device 0 over xGMI + a de-interleave kernel.  BASELINE config 4. */
+    MIPT_MULTI_SAMPLES = 1   /* every device renders all pixels for a disjoint sample range with the per-sample seeds of
+                              * rt_compute.wgsl:102 (seed_mode is forced to MIPT_SEED_PER_SAMPLE: the pixel stream cannot be
+                              * entered mid-way) into un-normalised sums; ONE ncclReduce(sum, f32) to device 0, then / samples.
+                              * The f32 sum order differs from a sequential accumulation.  BASELINE config 5. */
+};
+
+typedef struct {
+    MiptStats total;              /* counters summed over devices; kernel_ms = the slowest device's trace kernel */
+    double    collective_ms;      /* gather/reduce + assemble (+ tonemap) on device 0's stream, HIP events */
+    double    wall_ms;            /* the whole call on the host clock, incl. the D2H copy of the outputs */
+    double    device_kernel_ms[8];/* trace-kernel time of devices 0..7 */
+    uint32_t  n_devices, reserved;
+} MiptMultiStats;
+
+/* device_ids: n_devices HIP device ordinals (NULL = 0..n_devices-1; n_devices 0 = every visible device).  Uploads one
+ * replica per device (concurrently) and creates the communicators. */
+int  mipt_multi_create(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);
+void mipt_multi_destroy(MiptMulti *multi);
+int  mipt_multi_device_count(const MiptMulti *multi);
+
+/* Renders one frame on all devices of `multi` into HOST buffers (either may be NULL) and blocks until done; same outputs
+ * as mipt_render.  `opt` describes the whole frame: tile_rank / tile_world / sample_begin and the PACKED / SUM / ACCUM
+ * flags must be 0 (the call owns the sharding); MIPT_FLAG_COUNT is honoured. */
+int  mipt_render_multi(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
+                       float *hdr_rgb, uint8_t *rgba8, MiptMultiStats *stats);
 
 /* ---- host-side restatements of the scene model that feeds the path ------------------- */
 

@@ -34,7 +34,8 @@ SHADING_CPU, SHADING_WGPU = 0, 1
 FLAG_COUNT, FLAG_PACKED, FLAG_SUM, FLAG_ACCUM = 1, 2, 4, 8
 CULL_MARGIN_SAFE = 0.0078125  # MIPT_CULL_MARGIN_SAFE
 
-OK, ERR_INVALID_ARG, ERR_HIP, ERR_SCENE_LIMIT, ERR_BVH, ERR_IO, ERR_STACK = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_SCENE_LIMIT, ERR_BVH, ERR_IO, ERR_STACK, ERR_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
+MULTI_TILES, MULTI_SAMPLES = 0, 1
 
 
 class MiptTexture(C.Structure):
@@ -67,6 +68,17 @@ class MiptStats(C.Structure):
         return d
 
 
+class MiptMultiStats(C.Structure):
+    _fields_ = [("total", MiptStats), ("collective_ms", C.c_double), ("wall_ms", C.c_double),
+                ("device_kernel_ms", C.c_double * 8), ("n_devices", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        d = self.total.as_dict()
+        d.update(collective_ms=self.collective_ms, wall_ms=self.wall_ms, n_devices=self.n_devices,
+                 device_kernel_ms=list(self.device_kernel_ms)[: self.n_devices])
+        return d
+
+
 # every symbol include/mipt.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "mipt_scene_create", "mipt_scene_destroy", "mipt_render", "mipt_render_device",
@@ -74,6 +86,7 @@ EXPORTS = [
     "mipt_camera_from_pose", "mipt_material_default", "mipt_last_error", "mipt_abi_version",
     "mipt_device_count", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
     "mipt_texture_load", "mipt_texture_free", "mipt_image_save_png",
+    "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_render_multi",
 ]
 
 _lib = None
@@ -137,6 +150,14 @@ def load() -> C.CDLL:
     lib.mipt_texture_free.restype = None
     lib.mipt_image_save_png.argtypes = [C.c_char_p, u32, u32, u32, vp]
     lib.mipt_image_save_png.restype = C.c_int
+    lib.mipt_multi_create.argtypes = [C.POINTER(MiptSceneDesc), vp, C.c_int, C.POINTER(vp)]
+    lib.mipt_multi_create.restype = C.c_int
+    lib.mipt_multi_destroy.argtypes = [vp]
+    lib.mipt_multi_destroy.restype = None
+    lib.mipt_multi_device_count.argtypes = [vp]
+    lib.mipt_multi_device_count.restype = C.c_int
+    lib.mipt_render_multi.argtypes = [vp, vp, C.POINTER(MiptOptions), u32, vp, vp, C.POINTER(MiptMultiStats)]
+    lib.mipt_render_multi.restype = C.c_int
     _lib = lib
     return lib
 

@@ -356,8 +356,10 @@ static int validate_options(const MiptOptions *opt) {
     return MIPT_OK;
 }
 
-int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
-                       float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats) {
+// `pack_single`: honour MIPT_FLAG_PACKED also at tile_world == 1 (mipt_render_multi with one device keeps the same
+// gather + unpack path as with eight); through the public entry PACKED at world 1 means full-frame, as documented.
+int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                            float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single) {
     if (!scene || !camera) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_device: null scene or camera");
     int rc = validate_options(opt);
     if (rc) return rc;
@@ -366,7 +368,7 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
     hipStream_t stream = (hipStream_t)hip_stream;
 
     const uint32_t world = opt->tile_world ? opt->tile_world : 1u;
-    const bool packed = (opt->flags & MIPT_FLAG_PACKED) != 0 && world > 1;
+    const bool packed = (opt->flags & MIPT_FLAG_PACKED) != 0 && (world > 1 || pack_single);
     if ((opt->flags & MIPT_FLAG_ACCUM) && !(opt->flags & MIPT_FLAG_SUM))
         return fail(MIPT_ERR_INVALID_ARG, "MIPT_FLAG_ACCUM needs MIPT_FLAG_SUM (a running sum, divided once at the end)");
     if (d_rgba8 && (packed || (opt->flags & MIPT_FLAG_SUM)))
@@ -453,6 +455,11 @@ int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOpt
         return fail(MIPT_ERR_STACK, "traversal stack overflowed %llu times (capacity %d; the reference panics at 32, ray.rs:85)",
                     hs.stack_overflows, mipt::kStackLds + mipt::kStackOvf);
     return MIPT_OK;
+}
+
+int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                       float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats) {
+    return mipt_render_device_impl(scene, camera, opt, d_hdr_rgb, d_rgba8, hip_stream, stats, false);
 }
 
 int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,

@@ -95,6 +95,7 @@ hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,
                           uint8_t *rgba8, hipStream_t stream);
 
+hipError_t launch_divide(float *hdr, unsigned long long n_floats, float divisor, hipStream_t stream);
 hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, float divisor, uint16_t *rgba16,
                               hipStream_t stream);
 

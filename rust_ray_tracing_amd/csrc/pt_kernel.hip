@@ -646,6 +646,17 @@ __global__ void unpack_tiles_kernel(const float *__restrict__ packed_all, uint32
     }
 }
 
+// ---- cpu.rs:60 on a reduced sum buffer: final_color /= samples (sample-sharded renders divide once, after the reduce) ----
+__global__ void divide_kernel(float *__restrict__ hdr, unsigned long long n_floats, float divisor) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_floats;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        hdr[i] = hdr[i] / divisor;
+}
+hipError_t launch_divide(float *hdr, unsigned long long n_floats, float divisor, hipStream_t stream) {
+    hipLaunchKernelGGL(divide_kernel, dim3(2048), dim3(256), 0, stream, hdr, n_floats, divisor);
+    return hipGetLastError();
+}
+
 // ---- cpu.rs:60-64 epilogue: (x scale) -> linear_to_srgb -> floor(x*255) clamp -> [r,g,b,255] ----
 __global__ void tonemap_kernel(const float *__restrict__ hdr, unsigned long long n, float divisor, uint32_t *__restrict__ rgba8) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -206,6 +206,24 @@ class Scene:  # scene.rs:12-19
         if self._handle is not None:
             L.load().mipt_scene_destroy(self._handle)
             self._handle = None
+        if getattr(self, "_multi", None) is not None:
+            L.load().mipt_multi_destroy(self._multi)
+            self._multi = None
+
+    def upload_multi(self, device_ids=None) -> C.c_void_p:
+        """One replica + RCCL communicator per device (mipt_multi_create); device_ids None = every visible device."""
+        key = None if device_ids is None else tuple(device_ids)
+        if getattr(self, "_multi", None) is not None and self._multi_key == key:
+            return self._multi
+        if getattr(self, "_multi", None) is not None:
+            L.load().mipt_multi_destroy(self._multi)
+            self._multi = None
+        h = C.c_void_p()
+        d = self.desc()
+        ids = None if device_ids is None else (C.c_int * len(device_ids))(*device_ids)
+        L.check(L.load().mipt_multi_create(C.byref(d), ids, 0 if device_ids is None else len(device_ids), C.byref(h)), "mipt_multi_create")
+        self._multi, self._multi_key = h, key
+        return h
 
     def __del__(self):
         try:
@@ -265,6 +283,23 @@ class Renderer:  # renderer.rs:8-85
         rc = L.load().mipt_render(handle, L.ptr(scene.camera.uniform), C.byref(opt),
                                   L.ptr(hdr) if want_hdr else None, L.ptr(rgba) if want_rgba8 else None, C.byref(st))
         L.check(rc, "mipt_render")
+        self.last_stats = st.as_dict()
+        return hdr, rgba, self.last_stats
+
+    def render_buffers_multi(self, scene: Scene, mode: int = L.MULTI_TILES, device_ids=None, want_hdr: bool = True,
+                             want_rgba8: bool = True, flags: int = 0):
+        """The same arm over all GPUs of the node in one call (mipt_render_multi): image tiles + one RCCL gather, or
+        sample ranges + one RCCL sum-reduce.  Returns (hdr, rgba8, stats dict)."""
+        o = self.options
+        w, h = o.output_image_dimensions
+        multi = scene.upload_multi(device_ids)
+        opt = make_options(w, h, o.samples, o.max_ray_depth, o.seed_mode, o.traversal, flags, cull_margin=o.cull_margin, shading=o.shading)
+        hdr = np.zeros((h, w, 3), dtype=np.float32) if want_hdr else None
+        rgba = np.zeros((h, w, 4), dtype=np.uint8) if want_rgba8 else None
+        st = L.MiptMultiStats()
+        rc = L.load().mipt_render_multi(multi, L.ptr(scene.camera.uniform), C.byref(opt), mode,
+                                        L.ptr(hdr) if want_hdr else None, L.ptr(rgba) if want_rgba8 else None, C.byref(st))
+        L.check(rc, "mipt_render_multi")
         self.last_stats = st.as_dict()
         return hdr, rgba, self.last_stats
 
