@@ -24,8 +24,8 @@
 #include <vector>
 
 void mipt_internal_set_error(const char *msg);
-int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt, float *d_hdr_rgb,
-                            uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single);
+extern "C" int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt, float *d_hdr_rgb,
+                                       uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single);
 
 struct MiptMulti {
     int n = 0;
