@@ -233,7 +233,7 @@ __device__ __forceinline__ int gl_checkint(uint32_t iy) {             // 0: not 
 __device__ __forceinline__ bool gl_zeroinfnan(uint32_t ix) { return 2u * ix - 1u >= 2u * 0x7f800000u - 1u; }
 __device__ __forceinline__ bool gl_issignalingf(float x) { return 2u * (__float_as_uint(x) ^ 0x00400000u) > 2u * 0x7fc00000u; }
 __device__ __forceinline__ float gl_xflowf(uint32_t sign, float y) { return (sign ? -y : y) * y; }   // math_errf.c
-__device__ __noinline__ float gl_powf(float x, float y) {
+__device__ __forceinline__ float gl_powf(float x, float y) {
     const float INF = __builtin_inff();
     uint32_t sign_bias = 0;
     uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
@@ -274,7 +274,7 @@ __device__ __noinline__ float gl_powf(float x, float y) {
     return gl_exp2_inline(ylogx, sign_bias);
 }
 // e_expf.c
-__device__ __noinline__ float gl_expf(float x) {
+__device__ __forceinline__ float gl_expf(float x) {
     const double xd = (double)x;
     const uint32_t abstop = gl_abstop12(x);
     if (abstop >= 0x42bu /* abstop12(88.0f) */) {
@@ -341,7 +341,13 @@ __device__ __forceinline__ uint32_t srgb_quantize(float c) {
 // tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
 __device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
     const float q0 = a * r;
+#if defined(MIPT_WHATIF_FDIV) && MIPT_WHATIF_FDIV == 2      // timing experiment only (wrong results): no correction
+    return q0;
+#endif
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
+#if defined(MIPT_WHATIF_FDIV) && MIPT_WHATIF_FDIV == 1      // timing experiment only: one correction
+    return q1;
+#endif
     return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
 }
 // u8 -> f32 / 255.0 (vec3.rs:252-260) with the same exact two-correction quotient as fdiv_ray: the numerator is an

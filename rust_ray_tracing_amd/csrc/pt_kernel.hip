@@ -136,7 +136,7 @@ __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uin
 struct V4 { float x, y, z, w; };
 __device__ __forceinline__ float w_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-__device__ __noinline__ V4 sample_texture_bilinear(const uint32_t *texels, uint32_t offset, uint32_t width, uint32_t height, float u, float v) {
+__device__ __forceinline__ V4 sample_texture_bilinear(const uint32_t *texels, uint32_t offset, uint32_t width, uint32_t height, float u, float v) {
     const long long W = width, H = height;                                   // textureSampleLevel: linear, repeat (gpu.rs:393-401)
     const float uu = u * (float)W - 0.5f, vv = v * (float)H - 0.5f;
     const float fu = floorf(uu), fv = floorf(vv);
@@ -187,8 +187,9 @@ __device__ __forceinline__ V3 sample_ggx_vndf(V3 ve, float ax, float ay, uint32_
     const V3 Nh = (T1 * t1 + T2 * t2) + Vh * k;
     return normalized(mk(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
 }
-__device__ __forceinline__ V3 cosine_sample_hemisphere(uint32_t &rng) {                          // rt_compute.wgsl:527-551
-    const float ux = rand_f32(rng), uy = rand_f32(rng);
+// cosine_sample_hemisphere (rt_compute.wgsl:527-551), split: the two RNG draws happen where the shader calls the function;
+// the direction itself is a pure function of them and is only evaluated on the branch that uses it.
+__device__ __forceinline__ V3 cosine_hemisphere_from(float ux, float uy) {
     const float ox = 2.0f * ux - 1.0f, oy = 2.0f * uy - 1.0f;
     float dx, dy;
     if (ox == 0.0f && oy == 0.0f) { dx = 0.0f; dy = 0.0f; }
@@ -202,7 +203,7 @@ __device__ __forceinline__ V3 cosine_sample_hemisphere(uint32_t &rng) {         
     return mk(dx, dy, z);
 }
 
-__device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ray_color, V3 &incoming, V3 &prev_hit_point,
+__device__ __forceinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ray_color, V3 &incoming, V3 &prev_hit_point,
                                         uint32_t depth, uint32_t &rng, float t, float u, float v, uint32_t best_tri, uint32_t &n_tex) {
     const float EPSILON = 0.0001f;
     const uint32_t tri = best_tri & ~kFrontBit;
@@ -256,16 +257,9 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
     const float p1 = 1.0f - dot(sampled_normal, neg_dir), p2 = p1 * p1;
     const float p5 = (p2 * p2) * p1;                                                   // schlick_fresnel, :553-555
     const V3 fresnel = mk(f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5);
-    const float two_ndi = 2.0f * dot(sampled_normal, d);
-    const V3 specular_dir = normalized(d - sampled_normal * two_ndi);                  // reflect
-    V3 transmitted_dir;
-    {
-        const float ndi = dot(sampled_normal, d);                                      // refract
-        const float k = 1.0f - ior * ior * (1.0f - ndi * ndi);
-        const V3 r = (k < 0.0f) ? mk(0.0f, 0.0f, 0.0f) : (d * ior - sampled_normal * (ior * ndi + __builtin_sqrtf(k)));
-        transmitted_dir = normalized(r);
-    }
-    const V3 diffuse_dir = normalized(to_world(tangent, bitangent, tbn_n, cosine_sample_hemisphere(rng)));
+    // The shader evaluates reflect / refract / cosine-hemisphere eagerly (:160-165) and then uses one of them; they are pure
+    // functions of values fixed here, so only the RNG draws keep their place and each direction is computed on its branch.
+    const float hemi_ux = rand_f32(rng), hemi_uy = rand_f32(rng);                      // cosine_sample_hemisphere's draws
     bool specular = false, transmitted = false;                                        // select_bsdf, :231-248
     {
         const float r = rand_f32(rng);
@@ -278,7 +272,10 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
     if (fl < r2 && !specular) {                                                        // :167-186
         ray_color = ray_color * base;
         if (transmitted) {
-            new_dir = transmitted_dir;
+            const float ndi = dot(sampled_normal, d);                                  // refract
+            const float k = 1.0f - ior * ior * (1.0f - ndi * ndi);
+            const V3 r = (k < 0.0f) ? mk(0.0f, 0.0f, 0.0f) : (d * ior - sampled_normal * (ior * ndi + __builtin_sqrtf(k)));
+            new_dir = normalized(r);
             if (dot(new_dir, normal) > 0.0f) return true;
             V3 absorption = mk(1.0f, 1.0f, 1.0f);
             if (!front_face)
@@ -286,11 +283,12 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
                                 gl_expf(-(1.0f - base.z) * transmitted_distance));
             ray_color = ray_color * absorption;
         } else {
-            new_dir = diffuse_dir;
+            new_dir = normalized(to_world(tangent, bitangent, tbn_n, cosine_hemisphere_from(hemi_ux, hemi_uy)));
         }
     } else {                                                                           // :187-196
         if (specular) ray_color = ray_color * fresnel;
-        new_dir = specular_dir;
+        const float two_ndi = 2.0f * dot(sampled_normal, d);
+        new_dir = normalized(d - sampled_normal * two_ndi);                            // reflect
         if (dot(new_dir, normal) < 0.0f) return true;
     }
     float rr = 1.0f;                                                                   // Russian roulette, :198-207
@@ -310,8 +308,11 @@ __device__ __noinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 &ra
 #ifndef MIPT_MIN_WAVES_PER_SIMD
 #define MIPT_MIN_WAVES_PER_SIMD 5      // CPU-backend shading: 96 VGPRs, no scratch (97 without the bound = 4 waves)
 #endif
+#ifndef MIPT_MIN_WAVES_SHADING1
+#define MIPT_MIN_WAVES_SHADING1 4      // wgpu-shader shading, fully inlined: 128 VGPRs + 56 B scratch (146 without the bound = 3 waves)
+#endif
 template <bool COUNT, bool CULL, bool LDS_TOP, int SHADING>
-__global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SIMD : 1) void pt_trace_kernel(DevScene sc, DevParams pr) {
+__global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SIMD : MIPT_MIN_WAVES_SHADING1) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];   // row kStackLds: scratch target of the branch-free push
     __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
     __shared__ double s_logtab[32];                                    // __logf_data.tab (16 x {invc, logc}) for gl_log10f
@@ -521,11 +522,22 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SI
                 const float4 *q = s_top + (pair & 0xffffu) * 4u;
                 r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3];
             } else {
+#if defined(MIPT_WHATIF_LOADS) && MIPT_WHATIF_LOADS == 2       // timing experiment only (wrong results): half the load instructions
+                r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = r0; r3 = r1;
+                r2.w = r0.w; r3.w = r1.w;
+#else
                 r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
                 r3 = ldg4(geom, voff + 48u);                             // tri_pos is padded by one float4
+#endif
             }
             // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
             // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
+#ifdef MIPT_WHATIF_EXTRA_LOADS                                  // timing experiment only: re-load quarters of the SAME record (same lines)
+            {
+                float4 x0 = ldg4(geom, voff), x1 = ldg4(geom, voff + 32u);
+                asm volatile("" :: "v"(x0.x), "v"(x1.x));
+            }
+#endif
             asm volatile("" ::: "memory");
             if (COUNT && DIAG_STAMPS) {      // diagnostic only: split an iteration into memory wait and the rest
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,6 +568,14 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SI
                 const float max_d = best_t * pr.cull_scale;
                 float d1, d2;
                 slab_pair<CULL>(o, d, rd, dir_safe, r0, r1, r2, r3, max_d, d1, d2);
+#ifdef MIPT_WHATIF_EXTRA_VALU                                   // timing experiment only: N extra dependent FMAs per inner step
+                {
+                    float dummy = r0.x;
+#pragma unroll
+                    for (int k = 0; k < MIPT_WHATIF_EXTRA_VALU; k++) dummy = __builtin_fmaf(dummy, 1.0001f, o.x);
+                    if (dummy == 123.456f) d1 = d2;
+                }
+#endif
                 uint32_t a1 = __float_as_uint(r0.w), n1 = __float_as_uint(r1.w);
                 uint32_t a2 = __float_as_uint(r2.w), n2 = __float_as_uint(r3.w);
                 uint32_t w2 = 1u;
