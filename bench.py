@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- the headline metric of BASELINE.json: Mray/s at 1920x1080, 8 spp on a Sponza-scale
-(~10 M-triangle) BVH, 1/2/4/8 GPUs, with the HBM roofline of the trace kernel and the CPU path
-timed beside it.
+(~10 M-triangle) BVH, 1/2/4/8 GPUs, with the roofline of the trace kernel and the CPU path timed beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode tiles|samples]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one full frame of the hot path: every rank traces its share of the 8x8 image tiles
-(scene replicated per GPU, inputs resident in HBM) and, for N > 1, the frame is assembled with one
-RCCL all-gather of the rank-packed tile slices plus a de-interleave kernel.  A "ray" is one
-traverse_bvh invocation (reference src/renderer/backend/cpu/ray.rs:150); ray counts come from the
-kernel's counting build on the same inputs (deterministic), run outside the timed region.
-Data is synthetic (no assets ship with the reference): the seeded "atrium" stand-in of
-rust_ray_tracing_amd/synth.py.  max_ray_depth = 64 is the reference's shipped value (src/main.rs:20).
+A "step" is one full frame of the hot path (scene replicated per GPU, inputs resident in HBM):
+  --mode tiles (default; BASELINE config 4's split and the metric's configuration): every rank traces its share of the
+      8x8 image tiles with the CPU backend's per-pixel seeds (reference src/renderer/backend/cpu.rs:28-29); for N > 1 the
+      frame is assembled with ONE RCCL all-gather of the rank-packed tile slices plus a de-interleave kernel.
+  --mode samples (BASELINE config 5's split): every rank traces ALL pixels for its share of the samples with the
+      per-sample seeds of rt_compute.wgsl:102 into un-normalised sums; ONE RCCL sum-reduce to rank 0, then / spp.
+With N > 1 the line also carries the other mode's rate ("other_mode"): the tile split is floored by the reference's
+sequential per-pixel RNG chain, the sample split is not.
+A "ray" is one traverse_bvh invocation (reference src/renderer/backend/cpu/ray.rs:150); ray counts come from the kernel's
+counting build on the same inputs (deterministic), run outside the timed region.  Data is synthetic (no assets ship with
+the reference): the seeded "atrium" stand-in of rust_ray_tracing_amd/synth.py.  max_ray_depth = 64 is the reference's
+shipped value (src/main.rs:20).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -33,42 +38,82 @@ import torch.distributed as dist  # noqa: E402
 
 import rust_ray_tracing_amd as rrt  # noqa: E402
 from rust_ray_tracing_amd import _lib as L  # noqa: E402
-from rust_ray_tracing_amd import synth  # noqa: E402
+from rust_ray_tracing_amd import sharding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+COUNT_KEYS = ("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels")
 
 
 def algorithmic_bytes(st: dict, n_samples: int) -> int:
-    """BASELINE.md section 3 / SURVEY.md 8(d): reference layouts (Node 32 B, Triangle 112 B, Material 80 B)."""
+    """BASELINE.md section 3 / SURVEY.md 8(d): bytes in the REFERENCE layouts (Node 32 B, Triangle 112 B, Material 80 B)."""
     return (32 * st["rays"] + 64 * st["inner_steps"] + 112 * st["tri_tests"] + 80 * st["hits"]
             + 4 * st["texel_fetches"] + 12 * n_samples)
 
 
-def pmc_traffic_bytes(n_tris_requested, w, h, spp, depth, traversal):
-    """HBM-side bytes per launch of the trace kernel from the committed rocprofv3 PMC summary (a separate --pmc run of
-    this same command, tools/pmc.sh): FETCH_SIZE [KiB] x 1024 x 2 (gfx950 counts a 128-B line fill as 64 B --
-    MI355X_MICROARCH.md, HBM; confirmed by TCC_MISS_sum x 128 B) + WRITE_SIZE [KiB] x 1024.  Only valid for the
-    configuration it was measured on (the default config M); otherwise None."""
-    if (n_tris_requested, w, h, spp, depth, traversal) != (10_000_000, 1920, 1080, 8, 64, "culled"):
-        return None
-    path = os.path.join(ROOT, "profiles", "r1_pmc_summary_final.csv")
+def device_bytes(st: dict, n_pixels: int) -> int:
+    """Bytes the kernel's loads actually request in the DEVICE layout: one 64-B record per inner step,
+    64 B per triangle test (48-B record + the shared fourth 16-B load), per hit 64 B attributes + 64 B material, 4 B per
+    texel, 12 B per pixel written."""
+    return (64 * st["inner_steps"] + 64 * st["tri_tests"] + 128 * st["hits"] + 4 * st["texel_fetches"] + 12 * n_pixels)
+
+
+def kernel_source_sha() -> str:
+    """Identifies the trace kernel's source: a committed PMC summary is only quoted if it was measured on this source."""
+    h = hashlib.sha256()
+    for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h"):
+        with open(os.path.join(ROOT, "rust_ray_tracing_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(n_tris_requested, w, h, spp, depth, traversal, mode):
+    """Memory-side bytes per launch of the trace kernel from the committed rocprofv3 PMC summary (a separate --pmc run of this
+    same command, tools/pmc.sh): TCC_EA0_RDREQ_sum x 128 B + WRITE_SIZE.  Every read request is a 128-B line fill -- also for
+    this kernel's per-lane 64-B gathers (calibrated: profiles/r2_fetch_calibration.csv; FETCH_SIZE tallies them at 64 B).
+    Quoted only for the configuration AND kernel source it was measured on; otherwise (None, reason)."""
+    if (n_tris_requested, w, h, spp, depth, traversal, mode) != (10_000_000, 1920, 1080, 8, 64, "culled", "tiles"):
+        return None, "not the profiled configuration"
+    path = os.path.join(ROOT, "profiles", "r2_pmc_summary.csv")
     try:
-        vals = {}
-        for line in open(path).read().splitlines()[1:]:
+        vals, meta = {}, {}
+        for line in open(path).read().splitlines():
+            if line.startswith("#"):
+                for kv in line[1:].split():
+                    if "=" in kv:
+                        k, v = kv.split("=", 1)
+                        meta[k] = v
+                continue
             parts = line.split(",")
-            vals[parts[1]] = float(parts[2])
-        return int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
-    except Exception:
-        return None
+            if len(parts) >= 3 and parts[0] != "kernel":
+                vals[parts[1]] = float(parts[2])
+        if meta.get("kernel_sha") != kernel_source_sha():
+            return None, f"profiles/r2_pmc_summary.csv was measured on kernel source {meta.get('kernel_sha')}, this is {kernel_source_sha()}"
+        return int(vals["TCC_EA0_RDREQ_sum"] * 128 + vals["WRITE_SIZE"] * 1024), meta
+    except Exception as e:  # noqa: BLE001
+        return None, f"no PMC summary: {e}"
 
 
 def baseline_metric():
     """The metric string of BASELINE.json (the file travels with the repo); the literal is its value at the time of writing."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as f:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
             return json.load(f)["metric"]
     except Exception:
         return "Mray/s at 1920x1080, 8 spp, Sponza BVH; 1/2/4/8-GPU scaling + % HBM roofline"
+
+
+def physical_cores() -> int:
+    try:
+        seen = set()
+        base = "/sys/devices/system/cpu"
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                p = os.path.join(base, d, "topology", "thread_siblings_list")
+                if os.path.exists(p):
+                    seen.add(open(p).read().strip())
+        return len(seen) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
 
 
 def log(rank, *a):
@@ -81,6 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["tiles", "samples"], default="tiles")
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -88,9 +134,11 @@ def main():
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--traversal", choices=["culled", "reference"], default="culled")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="target CPU time of the cpu_baseline sample (both thread counts together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="N > 1: skip the second (other sharding mode) measurement")
+    ap.add_argument("--no-render-multi", action="store_true", help="N = 1: skip the in-library mipt_render_multi (RCCL) leg")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 code path on fewer GPUs than ranks (collectives staged through host memory)")
     args = ap.parse_args()
@@ -129,142 +177,229 @@ def main():
     scene = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
     del tris
     t1 = time.time()
-    scene.build_bvh()
+    bvh_ms = scene.build_bvh_device(local_rank)        # identical tree to BVH::build (bvh.rs:13-161), tests/test_gpu_more.py
     t2 = time.time()
     scene.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
     handle = scene.upload(local_rank)
     t3 = time.time()
-    log(rank, f"scene: {len(scene.tris)} tris, {len(scene.bvh_nodes)} nodes; gen {t1 - t0:.1f}s, bvh {t2 - t1:.1f}s, upload {t3 - t2:.1f}s")
+    log(rank, f"scene: {len(scene.tris)} tris, {len(scene.bvh_nodes)} nodes; gen {t1 - t0:.1f}s, device bvh {bvh_ms:.0f} ms ({t2 - t1:.1f}s with transfers), upload {t3 - t2:.1f}s")
 
     w, h, spp, depth = args.width, args.height, args.spp, args.depth
     trav = L.TRAVERSAL_CULLED if args.traversal == "culled" else L.TRAVERSAL_REFERENCE
     n_pix = w * h
-    packed = world > 1
-    flags = L.FLAG_PACKED if packed else 0
-    n_slot = int(lib.mipt_packed_pixels(w, h, world)) if packed else n_pix
-    d_local = torch.empty(n_slot * 3, dtype=torch.float32, device=dev)
-    d_all = torch.empty(world * n_slot * 3, dtype=torch.float32, device=dev) if packed else None
-    d_frame = torch.empty(n_pix * 3, dtype=torch.float32, device=dev) if packed else d_local
     cam_ptr = L.ptr(scene.camera.uniform)
     stream = torch.cuda.current_stream(dev)
+    n_slot = int(lib.mipt_packed_pixels(w, h, world)) if world > 1 else n_pix
+    d_local = torch.empty(max(n_slot, n_pix) * 3, dtype=torch.float32, device=dev)
+    d_all = torch.empty(world * n_slot * 3, dtype=torch.float32, device=dev) if world > 1 else None
+    d_frame = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+    s_begin, s_count = sharding.sample_ranges(spp, world)[rank]
 
-    def render(extra_flags=0, traversal=trav, out=None):
-        opt = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM, traversal, flags | extra_flags, rank, world,
-                               cull_margin=L.CULL_MARGIN_SAFE)
+    def render(mode, extra_flags=0, traversal=trav, out=None):
+        """One launch of this rank's share in `mode`; returns MiptStats as a dict."""
+        if mode == "tiles":
+            opt = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM, traversal, (L.FLAG_PACKED if world > 1 else 0) | extra_flags,
+                                   rank, world, cull_margin=L.CULL_MARGIN_SAFE)
+        else:
+            opt = rrt.make_options(w, h, max(s_count, 1), depth, L.SEED_PER_SAMPLE, traversal, L.FLAG_SUM | extra_flags,
+                                   sample_begin=s_begin, cull_margin=L.CULL_MARGIN_SAFE)
         st = L.MiptStats()
         buf = d_local if out is None else out
         L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt), C.c_void_p(buf.data_ptr()), None,
                                        C.c_void_p(stream.cuda_stream), C.byref(st)), "mipt_render_device")
         return st.as_dict()
 
-    def step():
-        st = render()
-        if packed and on_host:
-            c_all = torch.empty(d_all.shape, dtype=d_all.dtype)
-            dist.all_gather_into_tensor(c_all, d_local.cpu())
-            d_all.copy_(c_all)
-        elif packed:
-            dist.all_gather_into_tensor(d_all, d_local)
-        if packed:
-            L.check(lib.mipt_unpack_tiles(C.c_void_p(d_all.data_ptr()), w, h, world, C.c_void_p(d_frame.data_ptr()),
-                                          C.c_void_p(stream.cuda_stream)), "mipt_unpack_tiles")
+    def step(mode):
+        if mode == "samples" and s_count == 0:                      # more ranks than samples: this rank contributes zeros
+            d_local.zero_()
+            st = {"kernel_ms": 0.0}
+        else:
+            st = render(mode)
+        if mode == "tiles":
+            if world > 1:
+                part = d_local[: n_slot * 3]
+                if on_host:
+                    c_all = torch.empty(d_all.shape, dtype=d_all.dtype)
+                    dist.all_gather_into_tensor(c_all, part.cpu())
+                    d_all.copy_(c_all)
+                else:
+                    dist.all_gather_into_tensor(d_all, part)
+                L.check(lib.mipt_unpack_tiles(C.c_void_p(d_all.data_ptr()), w, h, world, C.c_void_p(d_frame.data_ptr()),
+                                              C.c_void_p(stream.cuda_stream)), "mipt_unpack_tiles")
+            else:
+                d_frame.copy_(d_local[: n_pix * 3])
+        else:
+            part = d_local[: n_pix * 3]
+            if world > 1:
+                if on_host:
+                    c = part.cpu()
+                    dist.reduce(c, dst=0, op=dist.ReduceOp.SUM)
+                    part.copy_(c)
+                else:
+                    dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)   # ONE ncclReduce(sum, f32) of the HDR sums
+            torch.div(part, float(spp), out=d_frame)                 # cpu.rs:60, once, on the reduced sum (rank 0's is the frame)
         return st
 
-    # ---- counting build, outside the timed region (deterministic: same counts as the timed launches) ----
-    cst = render(extra_flags=L.FLAG_COUNT)
-    counts = torch.tensor([cst[k] for k in ("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels")],
-                          dtype=torch.int64, device=dev)
-    local_counts = {k: int(v) for k, v in zip(("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels"), counts.tolist())}
-    if world > 1:
-        all_reduce_(counts)
-    tot = {k: int(v) for k, v in zip(("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels"), counts.tolist())}
-    assert tot["pixels"] == n_pix, (tot["pixels"], n_pix)
-    log(rank, f"counts: {tot}")
+    def measure(mode):
+        # counting build, outside the timed region (deterministic: same counts as the timed launches)
+        if mode == "samples" and s_count == 0:
+            cst = {k: 0 for k in COUNT_KEYS}
+        else:
+            cst = render(mode, extra_flags=L.FLAG_COUNT)
+        counts = torch.tensor([cst[k] for k in COUNT_KEYS], dtype=torch.int64, device=dev)
+        local_counts = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
+        if world > 1:
+            all_reduce_(counts)
+        tot = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
+        want_pixels = n_pix if mode == "tiles" else n_pix * min(world, spp)
+        assert tot["pixels"] == want_pixels, (tot["pixels"], want_pixels)
+        for _ in range(args.warmup):
+            step(mode)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t_start = time.perf_counter()
+        kernel_ms = []
+        for _ in range(args.steps):
+            kernel_ms.append(step(mode)["kernel_ms"])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t_start
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            all_reduce_(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), tot, local_counts, kernel_ms
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t_start = time.perf_counter()
-    kernel_ms = []
-    for _ in range(args.steps):
-        kernel_ms.append(step()["kernel_ms"])
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t_start
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        all_reduce_(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
+    mode = args.mode
+    elapsed, tot, local_counts, kernel_ms = measure(mode)
+    log(rank, f"{mode}: counts {tot}")
     value = tot["rays"] * args.steps / elapsed / 1e6
+    frame_primary = d_frame.clone()
+
     # roofline of the dominant kernel (pt_trace_kernel), this rank's launches
-    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-    alg_bytes = algorithmic_bytes(local_counts, local_counts["pixels"] * spp)
+    avg_kernel_s = max(float(np.mean(kernel_ms)), 1e-9) * 1e-3
+    n_local_samples = local_counts["pixels"] * (spp if mode == "tiles" else s_count)
+    alg_bytes = algorithmic_bytes(local_counts, n_local_samples)
+    dev_bytes = device_bytes(local_counts, local_counts["pixels"])
     achieved = alg_bytes / avg_kernel_s / 1e9
+    traffic, prov = pmc_traffic(args.tris, w, h, spp, depth, args.traversal, mode) if world == 1 else (None, "N > 1")
+    seeds = "pixel-stream seeds (cpu.rs:28-29)" if mode == "tiles" else "per-sample seeds (rt_compute.wgsl:102)"
+    if mode == "tiles":
+        shard = f"8x8 image tiles round-robin over {world} rank(s)" + (", one RCCL all-gather of packed tile slices per frame" if world > 1 else "")
+    else:
+        shard = f"{spp} samples split over {world} rank(s), every rank all pixels" + (", one RCCL sum-reduce of the f32 HDR sums per frame" if world > 1 else "")
     result = {
         "metric": baseline_metric(),
         "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"atrium stand-in for Intel Sponza + curtains: {len(scene.tris)} tris, {len(scene.bvh_nodes)} BVH nodes, "
-                               f"{w}x{h}, {spp} spp, max_ray_depth {depth}, traversal {args.traversal}" + (f" (margin {L.CULL_MARGIN_SAFE})" if args.traversal == "culled" else "") + ", pixel-stream seeds",
-                   "sharding": f"8x8 image tiles round-robin over {world} rank(s)" + (", one RCCL all-gather of packed tile slices per frame" if packed else ""),
-                   "rays_per_frame": tot["rays"], "paths_per_frame": n_pix * spp},
+                               f"{w}x{h}, {spp} spp, max_ray_depth {depth}, traversal {args.traversal}"
+                               + (f" (margin {L.CULL_MARGIN_SAFE})" if args.traversal == "culled" else "") + f", {seeds}",
+                   "mode": mode, "sharding": shard, "rays_per_frame": tot["rays"], "paths_per_frame": n_pix * spp},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic_bytes(args.tris, w, h, spp, depth, args.traversal) if world == 1 else None,
-                     "traffic_note": "bytes per launch, rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate run: profiles/r1_pmc_summary_final.csv",
-                     "kernel": "pt_trace_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3),
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "bytes_per_ray": round(alg_bytes / max(local_counts["rays"], 1), 1),
+                     "basis": "ALGORITHMIC bytes in the reference's layouts (Node 32 B, Triangle 112 B, Material 80 B; SURVEY 8(d)) / kernel time. "
+                              "Not bytes moved: most are L1/L2 hits and the device layout is leaner -- see device_GBs (requested by the kernel's "
+                              "loads) and traffic (memory side, measured)",
+                     "traffic": traffic,
+                     "traffic_note": ("bytes per launch at the L2's memory side (HBM + Infinity Cache), rocprofv3 PMC in a separate run of this command: "
+                                      "TCC_EA0_RDREQ_sum x 128 B (every request is a 128-B line fill, calibrated for per-lane 64-B gathers in "
+                                      "profiles/r2_fetch_calibration.csv) + WRITE_SIZE; provenance in traffic_provenance") if traffic else
+                                     f"null: {prov}",
+                     "traffic_provenance": prov if traffic else None,
+                     "hbm_frac_measured": round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                     "kernel": "pt_trace_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3), "kernel_source_sha": kernel_source_sha(),
+                     "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": round(alg_bytes / max(local_counts["rays"], 1), 1),
+                     "device_bytes_per_launch": dev_bytes, "device_GBs": round(dev_bytes / avg_kernel_s / 1e9, 1),
                      "mray_s_kernel": round(local_counts["rays"] / avg_kernel_s / 1e6, 2)},
     }
 
+    # ---- N > 1: the other sharding mode, same steps (the tile split is floored by the per-pixel RNG chain; samples are not) ----
+    if world > 1 and not args.no_other_mode:
+        other = "samples" if mode == "tiles" else "tiles"
+        e2, tot2, _, k2 = measure(other)
+        result["other_mode"] = {"mode": other, "value": round(tot2["rays"] * args.steps / e2 / 1e6, 3), "unit": "Mray/s",
+                                "ms_per_step": round(e2 / args.steps * 1e3, 3), "rays_per_frame": tot2["rays"],
+                                "kernel_ms_rank0": round(float(np.mean(k2)), 3)}
+
     # ---- parity evidence at the bench size (outside the timed region) ----
     if rank == 0 and not args.no_parity:
-        par = {}
-        frame = d_frame.clone()
-        if world > 1:
+        par = {"against": "oracle/pt_oracle.c = C restatement of the rayon CPU backend incl. its libm (glibc 2.35 cosf/log10f/powf restated, "
+                          "== the host's libm on all 2^32 arguments: tests/test_libm_pin.py)"}
+        if world > 1 and mode == "tiles":
             # the all-gathered + de-interleaved frame must equal a frame rendered by this rank alone, bit for bit
             solo = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
             opt1 = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM, trav, 0, 0, 1, cull_margin=L.CULL_MARGIN_SAFE)
             L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt1), C.c_void_p(solo.data_ptr()), None,
                                            C.c_void_p(stream.cuda_stream), None), "mipt_render_device")
             torch.cuda.synchronize(dev)
-            par["gathered_frame_equals_single_gpu_frame"] = bool(torch.equal(frame.view(torch.int32), solo.view(torch.int32)))
+            par["gathered_frame_equals_single_gpu_frame"] = bool(torch.equal(frame_primary.view(torch.int32), solo.view(torch.int32)))
             del solo
-        if world == 1 and args.traversal == "culled":
-            ref_buf = torch.empty_like(d_local)
-            render(traversal=L.TRAVERSAL_REFERENCE, out=ref_buf)
+        if world > 1 and mode == "samples":
+            solo = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+            opt1 = rrt.make_options(w, h, spp, depth, L.SEED_PER_SAMPLE, trav, 0, cull_margin=L.CULL_MARGIN_SAFE)
+            L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt1), C.c_void_p(solo.data_ptr()), None,
+                                           C.c_void_p(stream.cuda_stream), None), "mipt_render_device")
             torch.cuda.synchronize(dev)
-            par["culled_equals_reference_traversal"] = bool(torch.equal(frame.view(torch.int32), ref_buf.view(torch.int32)))
+            par["reduced_frame_max_rel_diff_vs_single_gpu"] = float(((frame_primary - solo).abs() / solo.abs().clamp_min(1e-6)).max().item())
+            del solo
+        if world == 1 and args.traversal == "culled" and mode == "tiles":
+            ref_buf = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+            render("tiles", traversal=L.TRAVERSAL_REFERENCE, out=ref_buf)
+            torch.cuda.synchronize(dev)
+            par["culled_equals_reference_traversal"] = bool(torch.equal(frame_primary.view(torch.int32), ref_buf.view(torch.int32)))
             del ref_buf
         result["parity"] = par
+
+    # ---- N = 1: the in-library multi-GPU path (mipt_render_multi: RCCL communicator + gather / reduce behind the C ABI) ----
+    if rank == 0 and world == 1 and not args.no_render_multi:
+        try:
+            r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h), output_image_path="/dev/null",
+                                                     traversal=trav, cull_margin=L.CULL_MARGIN_SAFE))
+            hdr_m, _, mst = r.render_buffers_multi(scene, mode=L.MULTI_TILES if mode == "tiles" else L.MULTI_SAMPLES, device_ids=[local_rank],
+                                                   want_rgba8=False)
+            same = bool(np.array_equal(hdr_m.reshape(-1).view(np.uint32), frame_primary.cpu().numpy().view(np.uint32)))
+            result["render_multi"] = {"entry": "mipt_render_multi (one process, ncclCommInitAll)", "n_devices": mst["n_devices"],
+                                      "kernel_ms": round(mst["kernel_ms"], 3), "collective_ms": round(mst["collective_ms"], 3),
+                                      "wall_ms_incl_d2h": round(mst["wall_ms"], 3), "equals_bench_frame": same}
+        except Exception as e:  # noqa: BLE001  -- the leg is evidence, not the metric
+            result["render_multi"] = {"error": str(e)[:200]}
 
     # ---- CPU baseline: the oracle (C restatement of the rayon backend) on a strided pixel sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc
         mats_arr = scene.materials_array()
+        seed_mode = 0 if mode == "tiles" else 1
 
-        def cpu(stride):
+        def cpu(stride, threads=0):
             return orc.render(scene.tris, scene.bvh_nodes, mats_arr, scene.textures, scene.camera.uniform, w, h, spp, depth,
-                              cull=0, pix_stride=stride, want_rgba8=False)
-        probe_stride = 8191
-        _, _, ps = cpu(probe_stride)
+                              cull=0, pix_stride=stride, want_rgba8=False, threads=threads, seed_mode=seed_mode)
+        _, _, ps = cpu(8191)
         rate = ps["rays"] / max(ps["seconds"], 1e-6)
-        want_rays = rate * args.cpu_seconds
-        stride = max(1, int(tot["rays"] / max(want_rays, 1)))
-        stride = stride | 1                       # odd stride: samples every image column
+        want_rays = rate * args.cpu_seconds / 2
+        stride = max(1, int(tot["rays"] / max(want_rays, 1))) | 1   # odd stride: samples every image column
         hdr_cpu, _, cs = cpu(stride)
-        result["cpu_baseline"] = {"value": round(cs["rays"] / cs["seconds"] / 1e6, 4), "unit": "Mray/s", "cores": cs["threads_used"],
-                                  "kind": "port",
+
+        def summary(s):
+            v = s["rays"] / s["seconds"] / 1e6
+            return {"value": round(v, 4), "threads": s["threads_used"], "per_thread_mray_s": round(v / s["threads_used"], 5),
+                    "seconds": round(s["seconds"], 2), "uniform_blocks": s["n_blocks"],
+                    "slowest_block_over_mean_block": round(s["block_sec_max"] / max(s["block_sec_mean"], 1e-9), 3)}
+        head = summary(cs)
+        phys = physical_cores()
+        result["cpu_baseline"] = {"value": head["value"], "unit": "Mray/s", "cores": cs["threads_used"], "kind": "port",
                                   "sample": f"every {stride}th pixel of the same frame ({cs['rays']} rays, {cs['seconds']:.1f} s), "
-                                            "C restatement of the reference's rayon backend (no t-max cull), all samples and bounces"}
+                                            "C restatement of the reference's rayon backend (no t-max cull), all samples and bounces, "
+                                            "uniform contiguous pixel blocks as cpu.rs:22-26",
+                                  "per_thread_mray_s": head["per_thread_mray_s"],
+                                  "slowest_block_over_mean_block": head["slowest_block_over_mean_block"]}
+        if phys and phys != cs["threads_used"]:
+            _, _, cp = cpu(stride, threads=phys)
+            result["cpu_baseline"]["physical_cores_run"] = summary(cp)
         if not args.no_parity:
-            got = d_frame.cpu().numpy().reshape(h, w, 3)
+            got = frame_primary.cpu().numpy().reshape(h, w, 3)
             idx = np.arange(0, n_pix, stride)
             a = got.reshape(-1, 3)[idx].view(np.uint32)
             b = hdr_cpu.reshape(-1, 3)[idx].view(np.uint32)

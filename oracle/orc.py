@@ -31,7 +31,8 @@ class OrcOptions(C.Structure):
 class OrcStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("inner_steps", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
                 ("texel_fetches", C.c_uint64), ("stack_overflows", C.c_uint64), ("max_stack", C.c_uint64),
-                ("tex_clamped", C.c_uint64), ("seconds", C.c_double), ("threads_used", C.c_uint32), ("_pad", C.c_uint32)]
+                ("tex_clamped", C.c_uint64), ("seconds", C.c_double), ("threads_used", C.c_uint32), ("n_blocks", C.c_uint32),
+                ("block_sec_max", C.c_double), ("block_sec_mean", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "_pad"}

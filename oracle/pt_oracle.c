@@ -647,15 +647,23 @@ static void *worker(void *arg) {
     cx.cull = (int)job->opt.cull; cx.libm = (int)job->opt.libm;
     cx.cull_scale = 1.0f + job->opt.cull_margin;
     uint64_t stride = job->opt.pix_stride ? job->opt.pix_stride : 1;
+    uint32_t blk_n = 0; double blk_sum = 0.0, blk_max = 0.0;
     for (;;) {
         /* rayon's by_uniform_blocks (cpu.rs:22-26): contiguous blocks of w*h/T pixel indices */
         uint64_t b = __atomic_fetch_add(&job->next_block, 1, __ATOMIC_RELAXED);
         uint64_t lo = b * job->block;
         if (lo >= job->n_items) break;
         uint64_t hi = lo + job->block; if (hi > job->n_items) hi = job->n_items;
+        struct timespec b0, b1;
+        clock_gettime(CLOCK_MONOTONIC, &b0);
         for (uint64_t i = lo; i < hi; i++) render_pixel(job, job->opt.pix_begin + i * stride, &cx);
+        clock_gettime(CLOCK_MONOTONIC, &b1);
+        const double bs = (double)(b1.tv_sec - b0.tv_sec) + 1e-9 * (double)(b1.tv_nsec - b0.tv_nsec);
+        blk_n++; blk_sum += bs; if (bs > blk_max) blk_max = bs;
     }
     pthread_mutex_lock(&job->mu);
+    job->total.n_blocks += blk_n; job->total.block_sec_mean += blk_sum;      /* sum here, divided in orc_render */
+    if (blk_max > job->total.block_sec_max) job->total.block_sec_max = blk_max;
     job->total.rays += cx.s.rays; job->total.inner_steps += cx.s.inner_steps;
     job->total.tri_tests += cx.s.tri_tests; job->total.hits += cx.s.hits;
     job->total.texel_fetches += cx.s.texel_fetches; job->total.stack_overflows += cx.s.stack_overflows;
@@ -724,6 +732,7 @@ int orc_render(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, u
     pthread_mutex_destroy(&job.mu);
     if (stats) {
         *stats = job.total;
+        if (stats->n_blocks) stats->block_sec_mean /= (double)stats->n_blocks;
         stats->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         stats->threads_used = T;
     }

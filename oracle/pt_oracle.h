@@ -97,7 +97,9 @@ typedef struct {
     uint64_t tex_clamped;     /* texel index clamped (reference would panic, T10)      */
     double   seconds;         /* wall time of the pixel loop                           */
     uint32_t threads_used;
-    uint32_t _pad;
+    uint32_t n_blocks;        /* uniform pixel blocks handed out (cpu.rs:22-26)        */
+    double   block_sec_max;   /* slowest block                                         */
+    double   block_sec_mean;  /* mean block time: max/mean = the imbalance rayon's by_uniform_blocks leaves */
 } OrcStats;
 
 /* bvh.rs:13-161.  Reorders tris in place, writes <= 2*n-1 nodes. */

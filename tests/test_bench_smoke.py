@@ -1,4 +1,5 @@
-"""-m gpu: bench.py end to end on a tiny configuration -- the JSON contract the driver parses."""
+"""-m gpu: bench.py end to end on a tiny configuration -- the JSON contract the driver parses, both sharding modes, the
+in-library RCCL leg, and a two-rank rehearsal (gloo: both ranks share the one GPU of the box)."""
 import json
 import os
 import subprocess
@@ -7,25 +8,55 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--tris", "20000", "--width", "320", "--height", "184", "--spp", "2", "--depth", "8", "--steps", "2", "--warmup", "1",
+         "--cpu-seconds", "0.5", "--tex-size", "32"]
+
+
+def _run(cmd, **kw):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, **kw)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
 
 @pytest.mark.gpu
 def test_bench_json_contract(built):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tris", "20000", "--width", "320", "--height", "184",
-                          "--spp", "2", "--depth", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--tex-size", "32"],
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
     assert r["unit"] == "Mray/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["vs_baseline"] is None and r["dtype"] == "f32"
-    assert r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"] and r["config"]["mode"] == "tiles"
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["traffic"] is None                       # PMC traffic is only quoted for the configuration it was measured on
+    assert rf["traffic"] is None and rf["traffic_note"].startswith("null")   # PMC traffic is only quoted for the configuration AND source it was measured on
+    assert "ALGORITHMIC" in rf["basis"] and rf["device_bytes_per_launch"] > 0 and len(rf["kernel_source_sha"]) == 16
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["per_thread_mray_s"] > 0 and cb["slowest_block_over_mean_block"] >= 1.0
     assert r["parity"]["culled_equals_reference_traversal"] is True and r["parity"]["oracle_bit_exact_on_sample"] is True
+    assert "glibc" in r["parity"]["against"]
+    assert r["render_multi"]["equals_bench_frame"] is True and r["render_multi"]["n_devices"] == 1 and r["render_multi"]["collective_ms"] > 0
     assert r["value"] > 0 and r["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_samples_mode(built):
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "samples"] + SMALL)
+    assert r["config"]["mode"] == "samples" and "per-sample seeds" in r["config"]["workload"]
+    assert r["parity"]["oracle_bit_exact_on_sample"] is True and r["render_multi"]["equals_bench_frame"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tiles", "samples"])
+def test_bench_two_ranks_rehearsal(built, mode):
+    """The N > 1 code path with world_size 2 (collectives over gloo, both ranks on the one GPU): gathered / reduced frame vs
+    the single-GPU frame, and the other mode's rate in the same line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29611" if mode == "tiles" else "29612", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+              "--mode", mode] + SMALL, env=env)
+    assert r["n_gpus"] == 2 and r["config"]["mode"] == mode and r["other_mode"]["mode"] != mode and r["other_mode"]["value"] > 0
+    if mode == "tiles":
+        assert r["parity"]["gathered_frame_equals_single_gpu_frame"] is True
+    else:
+        assert r["parity"]["reduced_frame_max_rel_diff_vs_single_gpu"] < 1e-5
