@@ -1,7 +1,10 @@
 // bvh_build_device.hip -- BVH::build (reference src/bvh.rs:13-161) on the GPU, emitting the IDENTICAL node array and
 // triangle order as the host restatement (bvh_build.cpp) and the reference.  SURVEY 8(f) rank 4.
 //
-// Level-synchronous: one 256-thread workgroup per node of the current level.
+// Level-synchronous.  Every level's nodes are sorted into classes as they are created (device-side lists, no empty
+// workgroups): > 32768 triangles -> many workgroups per node; 513..32768 -> one 256-thread workgroup per node (the steps
+// below); 17..512 -> one WAVE per node (same steps with wave-level reductions, no block barriers, 4 nodes per workgroup);
+// <= 16 -> one thread per node running the reference's loops as written.
 //   1. centroid range per axis (block reduction; f32 min/max are exact and order-independent)
 //   2. "first plane the centroid is below" binning with the reference's own plane values and `<` comparisons
 //      (bvh.rs:82-84,147), per-bin boxes and counts through LDS integer atomics on order-preserving keys
@@ -34,6 +37,13 @@ constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kBig = 32768;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
 constexpr uint32_t kChunk = 8192;
 constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
+constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
+constexpr uint32_t kWaveMax = 512;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
+enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2 };
+// per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
+// children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
+struct Ctrl { uint32_t n_nodes; uint32_t pad; uint32_t cnt[2][3]; };
+struct Lists { uint32_t *l[2][3]; };
 
 struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
 struct BNode {
@@ -52,6 +62,46 @@ __device__ __forceinline__ float funkey(uint32_t k) { return __uint_as_float((k 
 __device__ __forceinline__ float box_area(const float *lo, const float *hi) {        // Node::surface_area, bvh.rs:196-203
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     return (ex * ez) + (ex * ey) + (ez * ey);
+}
+
+// Queue the two children of every active lane for the next level.  One atomic per class per wave: the lanes are ranked
+// with ballots (a per-lane atomicAdd on a per-lane class counter is not aggregated by the compiler and serialises in L2:
+// measured 30x slower on the deep levels).  Works under divergence -- only the lanes that reach this point take part.
+__device__ __forceinline__ uint32_t node_class(uint32_t n) { return n > kBig ? 3u : (n > kWaveMax ? (uint32_t)CLS_BLOCK : (n > kTiny ? (uint32_t)CLS_WAVE : (uint32_t)CLS_TINY)); }
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint32_t parity, uint32_t base_idx, uint32_t na, uint32_t nb) {
+    const uint32_t ca = node_class(na), cb = node_class(nb);
+    const unsigned long long active = __ballot(true);
+    const int leader = (int)__ffsll((long long)active) - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t c = 0; c < 3u; c++) {                    // class 3 (> kBig) is found by the host on the top levels
+        const unsigned long long ma = __ballot(ca == c), mb = __ballot(cb == c);
+        const uint32_t tot = (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
+        if (tot == 0u) continue;
+        uint32_t slot0 = 0;
+        if ((int)lane == leader) slot0 = atomicAdd(&ctrl->cnt[parity][c], tot);
+        slot0 = __shfl(slot0, leader);
+        uint32_t *list = ls.l[parity][c];
+        if (ca == c) list[slot0 + mask_rank(ma)] = base_idx;
+        if (cb == c) list[slot0 + (uint32_t)__popcll(ma) + mask_rank(mb)] = base_idx + 1u;
+    }
+}
+struct Box3 { float lx, ly, lz, hx, hy, hz; };      // passed by value: keeps the callers' boxes in registers (pointer parameters made
+                                                    // the one-thread-per-node kernel's locals spill into 40 KB of LDS per workgroup)
+__device__ __forceinline__ void emit_children(BNode *bn, Ctrl *ctrl, const Lists &ls, uint32_t next_parity, uint32_t node_i,
+                                              Box3 A, Box3 B, uint32_t first, uint32_t k, uint32_t n) {
+    const uint32_t base = atomicAdd(&ctrl->n_nodes, 2u);
+    BNode a, b;
+    a.lo[0] = A.lx; a.lo[1] = A.ly; a.lo[2] = A.lz; a.hi[0] = A.hx; a.hi[1] = A.hy; a.hi[2] = A.hz;
+    b.lo[0] = B.lx; b.lo[1] = B.ly; b.lo[2] = B.lz; b.hi[0] = B.hx; b.hi[1] = B.hy; b.hi[2] = B.hz;
+    a.first = first; a.n = k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
+    b.first = first + k; b.n = n - k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
+    bn[base] = a; bn[base + 1] = b;
+    bn[node_i].left = base;
+    queue_children(ctrl, ls, next_parity, base, k, n - k);
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total = block sum
@@ -95,11 +145,15 @@ __global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
     bn[0] = r;
 }
 
-// one workgroup per node of the level [lvl_begin, lvl_begin + gridDim.x)
-__global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
-                                                  uint32_t *hole_pos, uint32_t *tail_pos, uint32_t *n_nodes) {
-    __shared__ uint32_t s_key[3][8][6];      // per axis, per bin: lo.xyz (min keys), hi.xyz (max keys)
-    __shared__ uint32_t s_cnt[3][8];
+// one workgroup per node of this level's CLS_BLOCK list
+__global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__restrict__ list, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+                                                  uint32_t *hole_pos, uint32_t *tail_pos, Ctrl *ctrl, Lists ls, uint32_t next_parity) {
+    // per axis, per bin: lo.xyz (min keys), hi.xyz (max keys) and the count.  kCopies private copies (thread & 7 picks one,
+    // merged after the pass): with one copy the 64 lanes of a wave pile onto 8 addresses per atomic and serialise.
+    __shared__ uint32_t s_keyc[kCopies][3][8][6];
+    __shared__ uint32_t s_cntc[kCopies][3][8];
+    uint32_t(*s_key)[8][6] = s_keyc[0];
+    uint32_t(*s_cnt)[8] = s_cntc[0];
     __shared__ uint32_t s_cmin[3], s_cmax[3];
     __shared__ uint32_t s_ckey[2][6];        // child boxes (L, R)
     __shared__ uint32_t s_warp[4];
@@ -109,17 +163,16 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
     __shared__ float s_splitpos;
     __shared__ uint32_t s_k;
 
-    const uint32_t node_i = lvl_begin + blockIdx.x;
+    const uint32_t node_i = list[blockIdx.x];
     const BNode nd = bn[node_i];
     const uint32_t first = nd.first, n = nd.n, tid = threadIdx.x;
-    if (n > kBig || n <= kTiny) return;         // handled by the multi-workgroup kernels / the one-thread-per-node kernel
     const Proxy *in = pin + first;
     Proxy *out = pout + first;
 
     // ---- 1. centroid ranges (bvh.rs:67-77; f32::MIN == -f32::MAX) ----
     if (tid < 3) { s_cmin[tid] = 0xffffffffu; s_cmax[tid] = 0u; }
-    for (uint32_t i = tid; i < 3 * 8 * 6; i += kT) (&s_key[0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
-    for (uint32_t i = tid; i < 3 * 8; i += kT) (&s_cnt[0][0])[i] = 0u;
+    for (uint32_t i = tid; i < kCopies * 144u; i += kT) (&s_keyc[0][0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+    for (uint32_t i = tid; i < kCopies * 24u; i += kT) (&s_cntc[0][0][0])[i] = 0u;
     if (tid < 12) (&s_ckey[0][0])[tid] = ((tid % 6) < 3) ? 0xffffffffu : 0u;
     __syncthreads();
     {
@@ -143,10 +196,20 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
             if (!s_use[a]) continue;
             int k = 8;
             for (int j = 1; j < 8; j++) if (p.c[a] < s_pos[a][j]) { k = j; break; }
-            uint32_t *key = s_key[a][k - 1];
+            uint32_t *key = s_keyc[tid & (kCopies - 1u)][a][k - 1];
             for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
-            atomicAdd(&s_cnt[a][k - 1], 1u);
+            atomicAdd(&s_cntc[tid & (kCopies - 1u)][a][k - 1], 1u);
         }
+    }
+    __syncthreads();
+    if (tid < 144u) {                                   // merge the private copies into copy 0
+        uint32_t v = (&s_keyc[0][0][0][0])[tid];
+        for (uint32_t c = 1; c < kCopies; c++) { const uint32_t w = (&s_keyc[c][0][0][0])[tid]; v = ((tid % 6u) < 3u) ? (w < v ? w : v) : (w > v ? w : v); }
+        (&s_keyc[0][0][0][0])[tid] = v;
+    } else if (tid < 168u) {
+        uint32_t v = 0;
+        for (uint32_t c = 0; c < kCopies; c++) v += (&s_cntc[c][0][0])[tid - 144u];
+        (&s_cntc[0][0][0])[tid - 144u] = v;
     }
     __syncthreads();
     // ---- 3. SAH (bvh.rs:58-97, 138-161) ----
@@ -154,6 +217,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
         const float parent_cost = (float)n * box_area(nd.lo, nd.hi);
         float best_cost = F32_MAX, best_pos = 0.0f;
         int best_axis = 0;
+        uint32_t best_k = kNone;                        // #(c < pos) of the winning plane = the bins below it (planes increase with i)
         for (int a = 0; a < 3; a++) {
             if (!s_use[a]) continue;
             float rlo[8][3], rhi[8][3];
@@ -174,11 +238,11 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
                 lc += s_cnt[a][i - 1];
                 const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
                 const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
-                if (split_cost < best_cost) { best_axis = a; best_pos = s_pos[a][i]; best_cost = split_cost; }
+                if (split_cost < best_cost) { best_axis = a; best_pos = s_pos[a][i]; best_cost = split_cost; best_k = lc; }
             }
         }
         s_split = !(best_cost >= parent_cost);                                          // bvh.rs:94
-        s_axis = best_axis; s_splitpos = best_pos;
+        s_axis = best_axis; s_splitpos = best_pos; s_k = best_k;
     }
     __syncthreads();
     if (!s_split) {                                   // leaf: carry the range over unchanged
@@ -188,14 +252,15 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
     const int axis = s_axis;
     const float pos = s_splitpos;
     // ---- 4. the partition permutation ----
-    uint32_t cnt = 0;
-    for (uint32_t i = tid; i < n; i += kT) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
-    {
+    if (s_k == kNone) {                                 // only when no candidate was finite (NaN parent cost): count directly
+        __syncthreads();
+        uint32_t cnt = 0;
+        for (uint32_t i = tid; i < n; i += kT) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
         uint32_t tot;
         (void)block_exscan(cnt, s_warp, &tot);
         if (tid == 0) s_k = tot;
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t k = s_k;
     uint32_t *hp = hole_pos + first, *tp = tail_pos + first;
     // holes: positions p < k holding ">=", in increasing p  ->  hp[m] = p
@@ -275,13 +340,235 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
     __syncthreads();
     // ---- 5. children (bvh.rs:115-132) ----
     if (tid == 0) {
-        const uint32_t base = atomicAdd(n_nodes, 2u);
-        BNode a, b;
-        for (int q = 0; q < 3; q++) { a.lo[q] = funkey(s_ckey[0][q]); a.hi[q] = funkey(s_ckey[0][3 + q]); b.lo[q] = funkey(s_ckey[1][q]); b.hi[q] = funkey(s_ckey[1][3 + q]); }
-        a.first = first; a.n = k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
-        b.first = first + k; b.n = n - k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
-        bn[base] = a; bn[base + 1] = b;
-        bn[node_i].left = base;
+        const Box3 A{funkey(s_ckey[0][0]), funkey(s_ckey[0][1]), funkey(s_ckey[0][2]), funkey(s_ckey[0][3]), funkey(s_ckey[0][4]), funkey(s_ckey[0][5])};
+        const Box3 B{funkey(s_ckey[1][0]), funkey(s_ckey[1][1]), funkey(s_ckey[1][2]), funkey(s_ckey[1][3]), funkey(s_ckey[1][4]), funkey(s_ckey[1][5])};
+        emit_children(bn, ctrl, ls, next_parity, node_i, A, B, first, k, n);
+    }
+}
+
+// ---- nodes with 17..kWaveMax triangles: one wave64 per node, four nodes per workgroup; the same five steps with wave-level
+// reductions (f32 min/max and integer sums are exact in any order), a wave-private LDS region and no block barrier ----------
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ float wave_fmin(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_fmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t ballot_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// Each lane keeps its (up to kWaveMax / 64) proxies in registers: the node is read from memory once and written once.
+// Slot j of lane l is position p = 64 j + l, so "increasing p" is slot-major / lane-minor order.
+constexpr int kSlots = (int)(kWaveMax / 64u);
+constexpr int kWaveNodes = 8;                      // nodes (= waves) per workgroup of build_level_wave
+struct WaveSplit { bool split; uint32_t k; Box3 A, B; };
+__device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__restrict__ pin, Proxy *__restrict__ pout, uint32_t lane,
+                                               uint32_t (*key)[8][6], uint32_t (*cnt)[8], uint32_t *hp, uint32_t *tp) {
+    WaveSplit res;
+    res.split = false; res.k = 0;
+    res.A = Box3{0, 0, 0, 0, 0, 0}; res.B = res.A;
+    const uint32_t first = nd.first, n = nd.n;
+    const Proxy *in = pin + first;
+    Proxy *out = pout + first;
+
+    float c0[kSlots], c1[kSlots], c2[kSlots], l0[kSlots], l1[kSlots], l2[kSlots], h0[kSlots], h1[kSlots], h2[kSlots];
+    uint32_t id[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        const uint32_t p = 64u * (uint32_t)j + lane;
+        if (p < n) {
+            const Proxy e = in[p];
+            c0[j] = e.c[0]; c1[j] = e.c[1]; c2[j] = e.c[2]; l0[j] = e.lo[0]; l1[j] = e.lo[1]; l2[j] = e.lo[2];
+            h0[j] = e.hi[0]; h1[j] = e.hi[1]; h2[j] = e.hi[2]; id[j] = e.idx;
+        } else {                                                      // neutral for every min / max below
+            c0[j] = c1[j] = c2[j] = 0.0f; l0[j] = l1[j] = l2[j] = F32_MAX; h0[j] = h1[j] = h2[j] = -F32_MAX; id[j] = 0u;
+        }
+    }
+    // ---- 1. centroid ranges + planes (bvh.rs:67-84) ----
+    float cmin[3], cmax[3];
+    {
+        float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+#pragma unroll
+        for (int j = 0; j < kSlots; j++)
+            if (64u * (uint32_t)j + lane < n) {
+                mn[0] = fminf(mn[0], c0[j]); mx[0] = fmaxf(mx[0], c0[j]); mn[1] = fminf(mn[1], c1[j]); mx[1] = fmaxf(mx[1], c1[j]);
+                mn[2] = fminf(mn[2], c2[j]); mx[2] = fmaxf(mx[2], c2[j]);
+            }
+        for (int a = 0; a < 3; a++) { cmin[a] = wave_fmin(mn[a]); cmax[a] = wave_fmax(mx[a]); }
+    }
+    bool use[3];
+    float scale[3];
+    for (int a = 0; a < 3; a++) { use[a] = !(cmin[a] == cmax[a]); scale[a] = (cmax[a] - cmin[a]) / 8.0f; }
+    for (uint32_t i = lane; i < 144u; i += 64u) (&key[0][0][0])[i] = ((i % 6u) < 3u) ? 0xffffffffu : 0u;
+    if (lane < 24u) (&cnt[0][0])[lane] = 0u;
+    wave_sync();
+    // ---- 2. binning ----
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        if (64u * (uint32_t)j >= n) break;                           // wave-uniform
+        if (64u * (uint32_t)j + lane < n) {
+            const float cc[3] = {c0[j], c1[j], c2[j]};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if (!use[a]) continue;
+                int k = 8;
+                for (int q = 7; q >= 1; q--) if (cc[a] < cmin[a] + (float)q * scale[a]) k = q;      // first plane the centroid is below
+                uint32_t *kk = key[a][k - 1];
+                atomicMin(&kk[0], fkey(l0[j])); atomicMin(&kk[1], fkey(l1[j])); atomicMin(&kk[2], fkey(l2[j]));
+                atomicMax(&kk[3], fkey(h0[j])); atomicMax(&kk[4], fkey(h1[j])); atomicMax(&kk[5], fkey(h2[j]));
+                atomicAdd(&cnt[a][k - 1], 1u);
+            }
+        }
+    }
+    wave_sync();
+    // ---- 3. SAH: lane c < 21 evaluates candidate (axis c / 7, plane c % 7 + 1); the first strictly lower cost in
+    //         axis-major / plane-minor order wins (bvh.rs:86) = the lowest lane holding the minimum ----
+    float my_cost = F32_MAX, my_pos = 0.0f;
+    uint32_t my_k = 0;
+    if (lane < 21u) {
+        const int a = (int)(lane / 7u), i = (int)(lane % 7u) + 1;
+        if (use[a]) {
+            float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            float rlo[3] = {F32_MAX, F32_MAX, F32_MAX}, rhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            uint32_t lc = 0, rc = 0;
+            for (int b = 0; b < 8; b++) {                            // an empty bin's untouched keys decode to NaN, which fminf/fmaxf ignore
+                if (b < i) { for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(key[a][b][q])); lhi[q] = fmaxf(lhi[q], funkey(key[a][b][3 + q])); } lc += cnt[a][b]; }
+                else { for (int q = 0; q < 3; q++) { rlo[q] = fminf(rlo[q], funkey(key[a][b][q])); rhi[q] = fmaxf(rhi[q], funkey(key[a][b][3 + q])); } rc += cnt[a][b]; }
+            }
+            const float cost = (float)lc * box_area(llo, lhi) + (float)rc * box_area(rlo, rhi);
+            my_cost = (cost > 0.0f) ? cost : F32_MAX;
+            my_pos = cmin[a] + (float)i * scale[a];
+            my_k = lc;                                               // #(c < pos): bin b < i  <=>  c below plane i (planes increase with i)
+        }
+    }
+    const float best_cost = wave_fmin(my_cost);
+    int axis = 0;
+    float pos = 0.0f;
+    uint32_t k = 0;
+    bool k_known = false;
+    if (best_cost < F32_MAX) {                                       // else: nothing beat the initial f32::MAX -> axis 0, pos 0.0 (bvh.rs:60-62)
+        const unsigned long long m = __ballot(my_cost == best_cost);
+        const int win = (int)__ffsll((long long)m) - 1;
+        axis = win / 7;
+        pos = __shfl(my_pos, win);
+        k = __shfl(my_k, win);
+        k_known = true;
+    }
+    const float parent_cost = (float)n * box_area(nd.lo, nd.hi);
+    if (best_cost >= parent_cost) {                                  // leaf (bvh.rs:94): carry the range over unchanged
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const uint32_t p = 64u * (uint32_t)j + lane;
+            if (p < n) { Proxy e; e.c[0] = c0[j]; e.c[1] = c1[j]; e.c[2] = c2[j]; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j]; out[p] = e; }
+        }
+        return res;
+    }
+    // ---- 4. the partition permutation (closed form of bvh.rs:99-108, see the header comment) ----
+    bool less[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        const float c = axis == 0 ? c0[j] : (axis == 1 ? c1[j] : c2[j]);
+        less[j] = (64u * (uint32_t)j + lane < n) && (c < pos);
+    }
+    if (!k_known) {                                                  // NaN parent cost with no finite candidate: count directly
+        uint32_t cl = 0;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) cl += less[j] ? 1u : 0u;
+        k = wave_sum(cl);
+    }
+    uint32_t hole_rank[kSlots], tail_rank[kSlots];
+    uint32_t n_holes = 0;
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {                               // holes: positions < k holding ">=", increasing p
+        const uint32_t p = 64u * (uint32_t)j + lane;
+        const bool f = p < k && !less[j];
+        const unsigned long long m = __ballot(f);
+        hole_rank[j] = n_holes + ballot_rank(m);
+        if (f) hp[hole_rank[j]] = p;
+        n_holes += (uint32_t)__popcll(m);
+    }
+    uint32_t n_tail = 0;
+#pragma unroll
+    for (int j = kSlots - 1; j >= 0; j--) {                          // tail "<": positions >= k holding "<", decreasing p
+        const uint32_t p = 64u * (uint32_t)j + lane;
+        const bool f = p >= k && less[j];                            // (less[] is false beyond n)
+        const unsigned long long m = __ballot(f);
+        const unsigned long long above = lane == 63u ? 0ull : (m >> (lane + 1u));
+        tail_rank[j] = n_tail + (uint32_t)__popcll(above);
+        if (f) tp[tail_rank[j]] = p;
+        n_tail += (uint32_t)__popcll(m);
+    }
+    wave_sync();
+    const uint32_t t_last = n_holes ? tp[n_holes - 1u] : n;
+    float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        const uint32_t p = 64u * (uint32_t)j + lane;
+        if (p < n) {
+            uint32_t dest;
+            if (p < k) {
+                dest = p;
+                if (!less[j]) { const uint32_t mm = hole_rank[j]; dest = (mm ? tp[mm - 1u] : n) - 1u; }
+            } else {
+                if (less[j]) dest = hp[tail_rank[j]];
+                else if (p > t_last) dest = p - 1u;
+                else dest = (p == k) ? (t_last - 1u) : (p - 1u);
+            }
+            Proxy e; e.c[0] = c0[j]; e.c[1] = c1[j]; e.c[2] = c2[j]; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j];
+            out[dest] = e;
+            const int side = less[j] ? 0 : 1;
+            clo[side][0] = fminf(clo[side][0], l0[j]); clo[side][1] = fminf(clo[side][1], l1[j]); clo[side][2] = fminf(clo[side][2], l2[j]);
+            chi[side][0] = fmaxf(chi[side][0], h0[j]); chi[side][1] = fmaxf(chi[side][1], h1[j]); chi[side][2] = fmaxf(chi[side][2], h2[j]);
+        }
+    }
+    for (int sd = 0; sd < 2; sd++)
+        for (int q = 0; q < 3; q++) { clo[sd][q] = wave_fmin(clo[sd][q]); chi[sd][q] = wave_fmax(chi[sd][q]); }
+    if (k == 0u || k == n) return res;                               // bvh.rs:110-113 (cannot happen with a finite best cost)
+    res.split = true; res.k = k;
+    res.A = Box3{clo[0][0], clo[0][1], clo[0][2], chi[0][0], chi[0][1], chi[0][2]};
+    res.B = Box3{clo[1][0], clo[1][1], clo[1][2], chi[1][0], chi[1][1], chi[1][2]};
+    return res;
+}
+// ---- 5. children: the workgroup's waves hand their splits to wave 0, which allocates the child nodes and queues them with
+// ONE set of atomics per workgroup (a per-node atomic on the shared counters serialises in L2: ~6 ns each, which was the whole
+// cost of the deep levels) ----
+__global__ __launch_bounds__(64 * kWaveNodes, 4) void build_level_wave(BNode *bn, const uint32_t *__restrict__ list, uint32_t count,
+                                                                      const Proxy *__restrict__ pin, Proxy *__restrict__ pout, Ctrl *ctrl,
+                                                                      Lists ls, uint32_t next_parity) {
+    __shared__ uint32_t s_keyw[kWaveNodes][3][8][6];
+    __shared__ uint32_t s_cntw[kWaveNodes][3][8];
+    __shared__ uint32_t s_hp[kWaveNodes][kWaveMax], s_tp[kWaveNodes][kWaveMax];
+    __shared__ uint32_t s_node[kWaveNodes], s_first[kWaveNodes], s_n[kWaveNodes], s_k[kWaveNodes];
+    __shared__ Box3 s_box[kWaveNodes][2];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * (uint32_t)kWaveNodes + wv;
+    WaveSplit r;
+    r.split = false; r.k = 0;
+    uint32_t node_i = 0, first = 0, n = 0;
+    if (item < count) {                                              // wave-uniform
+        node_i = list[item];
+        const BNode nd = bn[node_i];
+        first = nd.first; n = nd.n;
+        r = wave_node(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+    }
+    if (lane == 0u) {
+        s_node[wv] = node_i; s_first[wv] = first; s_n[wv] = n; s_k[wv] = r.split ? r.k : 0u;     // k == 0 marks "no split"
+        s_box[wv][0] = r.A; s_box[wv][1] = r.B;
+    }
+    __syncthreads();
+    if (wv == 0u) {                                                  // lanes 0..kWaveNodes-1 each emit one node's children
+        const bool mine = lane < (uint32_t)kWaveNodes && s_k[lane] != 0u;
+        if (mine) emit_children(bn, ctrl, ls, next_parity, s_node[lane], s_box[lane][0], s_box[lane][1], s_first[lane], s_k[lane], s_n[lane]);
     }
 }
 
@@ -289,13 +576,13 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, uint32_t lvl_begin,
 __device__ __forceinline__ void grow(float *lo, float *hi, const Proxy &p) {
     for (int q = 0; q < 3; q++) { lo[q] = fminf(lo[q], p.lo[q]); hi[q] = fmaxf(hi[q], p.hi[q]); }
 }
-__global__ void build_level_tiny(BNode *bn, uint32_t lvl_begin, uint32_t lvl_end, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
-                                 uint32_t *n_nodes) {
-    const uint32_t node_i = lvl_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (node_i >= lvl_end) return;
+__global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, uint32_t count, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+                                 Ctrl *ctrl, Lists ls, uint32_t next_parity) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= count) return;
+    const uint32_t node_i = list[item];
     const BNode nd = bn[node_i];
     const uint32_t n = nd.n;
-    if (n > kTiny) return;
     const Proxy *in = pin + nd.first;
     Proxy *out = pout + nd.first;
     for (uint32_t i = 0; i < n; i++) out[i] = in[i];
@@ -337,11 +624,8 @@ __global__ void build_level_tiny(BNode *bn, uint32_t lvl_begin, uint32_t lvl_end
     for (int q = 0; q < 3; q++) { a.lo[q] = F32_MAX; a.hi[q] = -F32_MAX; b.lo[q] = F32_MAX; b.hi[q] = -F32_MAX; }
     for (uint32_t t = 0; t < k; t++) grow(a.lo, a.hi, out[t]);
     for (uint32_t t = k; t < n; t++) grow(b.lo, b.hi, out[t]);
-    const uint32_t base = atomicAdd(n_nodes, 2u);
-    a.first = nd.first; a.n = k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
-    b.first = nd.first + k; b.n = n - k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
-    bn[base] = a; bn[base + 1] = b;
-    bn[node_i].left = base;
+    emit_children(bn, ctrl, ls, next_parity, node_i, Box3{a.lo[0], a.lo[1], a.lo[2], a.hi[0], a.hi[1], a.hi[2]},
+                  Box3{b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]}, nd.first, k, n);
 }
 
 // ---- nodes with > kBig triangles: the same five steps, spread over one workgroup per kChunk elements ---------------------
@@ -356,6 +640,7 @@ struct BigState {
     int split, axis;
     float splitpos;
     uint32_t k, n_holes;
+    int k_known;                   // k taken from the bin counts of the winning plane (big_choose); else big_count counts it
     uint32_t ckey[2][6];
     float lo[3], hi[3];            // node bounds
 };
@@ -398,15 +683,16 @@ __global__ void big_planes(BigState *bs, uint32_t nb) {
     for (int i = 1; i < 8; i++) b->pos[a][i] = cmin + (float)i * scale;
 }
 __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
-    __shared__ uint32_t s_key[3][8][6];
-    __shared__ uint32_t s_cnt[3][8];
+    __shared__ uint32_t s_keyc[kCopies][3][8][6];
+    __shared__ uint32_t s_cntc[kCopies][3][8];
     __shared__ float s_pos[3][8];
     __shared__ int s_use[3];
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
-    for (uint32_t i = threadIdx.x; i < 144; i += kT) (&s_key[0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
-    if (threadIdx.x < 24) { (&s_cnt[0][0])[threadIdx.x] = 0u; (&s_pos[0][0])[threadIdx.x] = (&b->pos[0][0])[threadIdx.x]; }
+    for (uint32_t i = threadIdx.x; i < kCopies * 144u; i += kT) (&s_keyc[0][0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+    for (uint32_t i = threadIdx.x; i < kCopies * 24u; i += kT) (&s_cntc[0][0][0])[i] = 0u;
+    if (threadIdx.x < 24) (&s_pos[0][0])[threadIdx.x] = (&b->pos[0][0])[threadIdx.x];
     if (threadIdx.x < 3) s_use[threadIdx.x] = b->use[threadIdx.x];
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < c.len; i += kT) {
@@ -415,17 +701,23 @@ __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch,
             if (!s_use[a]) continue;
             int k = 8;
             for (int j = 1; j < 8; j++) if (p.c[a] < s_pos[a][j]) { k = j; break; }
-            uint32_t *key = s_key[a][k - 1];
+            uint32_t *key = s_keyc[threadIdx.x & (kCopies - 1u)][a][k - 1];
             for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
-            atomicAdd(&s_cnt[a][k - 1], 1u);
+            atomicAdd(&s_cntc[threadIdx.x & (kCopies - 1u)][a][k - 1], 1u);
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 144; i += kT) {
-        const uint32_t v = (&s_key[0][0][0])[i];
+    if (threadIdx.x < 144u) {
+        const uint32_t i = threadIdx.x;
+        uint32_t v = (&s_keyc[0][0][0][0])[i];
+        for (uint32_t cc = 1; cc < kCopies; cc++) { const uint32_t w = (&s_keyc[cc][0][0][0])[i]; v = ((i % 6u) < 3u) ? (w < v ? w : v) : (w > v ? w : v); }
         if ((i % 6) < 3) atomicMin(&(&b->key[0][0][0])[i], v); else atomicMax(&(&b->key[0][0][0])[i], v);
+    } else if (threadIdx.x < 168u) {
+        const uint32_t i = threadIdx.x - 144u;
+        uint32_t v = 0;
+        for (uint32_t cc = 0; cc < kCopies; cc++) v += (&s_cntc[cc][0][0])[i];
+        if (v) atomicAdd(&(&b->cnt[0][0])[i], v);
     }
-    if (threadIdx.x < 24 && (&s_cnt[0][0])[threadIdx.x]) atomicAdd(&(&b->cnt[0][0])[threadIdx.x], (&s_cnt[0][0])[threadIdx.x]);
 }
 __global__ void big_choose(BigState *bs, uint32_t nb) {                              // same expression order as build_level step 3
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +726,7 @@ __global__ void big_choose(BigState *bs, uint32_t nb) {                         
     const float parent_cost = (float)b->n * box_area(b->lo, b->hi);
     float best_cost = F32_MAX, best_pos = 0.0f;
     int best_axis = 0;
+    uint32_t best_k = kNone;
     for (int a = 0; a < 3; a++) {
         if (!b->use[a]) continue;
         float rlo[8][3], rhi[8][3];
@@ -453,17 +746,19 @@ __global__ void big_choose(BigState *bs, uint32_t nb) {                         
             lc += b->cnt[a][i - 1];
             const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
             const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
-            if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; }
+            if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; best_k = lc; }
         }
     }
     b->split = !(best_cost >= parent_cost);
     b->axis = best_axis; b->splitpos = best_pos;
+    b->k_known = best_k != kNone;
+    if (b->k_known) b->k = best_k;
 }
 __global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
     __shared__ uint32_t s_warp[4];
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
-    if (!b->split) return;
+    if (!b->split || b->k_known) return;
     const Proxy *in = pin + b->first + c.off;
     const int axis = b->axis; const float pos = b->splitpos;
     uint32_t cnt = 0;
@@ -591,17 +886,13 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
         if ((threadIdx.x % 6) < 3) atomicMin(&(&b->ckey[0][0])[threadIdx.x], v); else atomicMax(&(&b->ckey[0][0])[threadIdx.x], v);
     }
 }
-__global__ void big_finish(const BigState *bs, BNode *bn, uint32_t *n_nodes, uint32_t nb) {
+__global__ void big_finish(const BigState *bs, BNode *bn, Ctrl *ctrl, Lists ls, uint32_t next_parity, uint32_t nb) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nb || !bs[j].split) return;
     const BigState &s = bs[j];
-    const uint32_t base = atomicAdd(n_nodes, 2u);
-    BNode a, b;
-    for (int q = 0; q < 3; q++) { a.lo[q] = funkey(s.ckey[0][q]); a.hi[q] = funkey(s.ckey[0][3 + q]); b.lo[q] = funkey(s.ckey[1][q]); b.hi[q] = funkey(s.ckey[1][3 + q]); }
-    a.first = s.first; a.n = s.k; a.left = kNone; a.size = 0; a.dfs = 0; a.base = 0;
-    b.first = s.first + s.k; b.n = s.n - s.k; b.left = kNone; b.size = 0; b.dfs = 0; b.base = 0;
-    bn[base] = a; bn[base + 1] = b;
-    bn[s.node].left = base;
+    const Box3 A{funkey(s.ckey[0][0]), funkey(s.ckey[0][1]), funkey(s.ckey[0][2]), funkey(s.ckey[0][3]), funkey(s.ckey[0][4]), funkey(s.ckey[0][5])};
+    const Box3 B{funkey(s.ckey[1][0]), funkey(s.ckey[1][1]), funkey(s.ckey[1][2]), funkey(s.ckey[1][3]), funkey(s.ckey[1][4]), funkey(s.ckey[1][5])};
+    emit_children(bn, ctrl, ls, next_parity, s.node, A, B, s.first, s.k, s.n);
 }
 
 __global__ void sizes_level(BNode *bn, uint32_t begin, uint32_t end) {              // bottom-up: |desc(X)|
@@ -655,13 +946,14 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     Proxy *d_px[2] = {nullptr, nullptr};
     BNode *d_bn = nullptr;
     MiptNode *d_nodes = nullptr;
-    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_cnt = nullptr, *d_root = nullptr, *d_ids = nullptr, *d_cbeg = nullptr;
+    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_ids = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
+    Ctrl *d_ctrl = nullptr;
     BigState *d_big = nullptr;
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
-        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_cnt, d_root, d_ids, d_cbeg, d_big, d_chunks};
+        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_ids, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -677,7 +969,13 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipMalloc((void **)&d_nodes, (size_t)max_nodes * sizeof(MiptNode)));
     HIP_TRY(hipMalloc((void **)&d_hp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
-    HIP_TRY(hipMalloc((void **)&d_cnt, 4));
+    HIP_TRY(hipMalloc((void **)&d_ctrl, sizeof(Ctrl)));
+    // work lists: a level has at most min(2^level, n_tris) nodes; a class list never holds more nodes than triangles / its
+    // smallest node... sized by the simple bound n_tris + 1 per (parity, class)
+    const size_t list_cap = (size_t)n_tris + 1u;
+    HIP_TRY(hipMalloc((void **)&d_lists, 6 * list_cap * 4));
+    Lists ls;
+    for (int pa = 0; pa < 2; pa++) for (int c = 0; c < 3; c++) ls.l[pa][c] = d_lists + (size_t)(pa * 3 + c) * list_cap;
     HIP_TRY(hipMalloc((void **)&d_root, 24));
     HIP_TRY(hipMalloc((void **)&d_ids, (size_t)big_cap * 4));
     HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
@@ -687,15 +985,24 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    const uint32_t one = 1u;
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_cnt, &one, 4, hipMemcpyHostToDevice));
+    Ctrl hc;
+    memset(&hc, 0, sizeof hc);
+    hc.n_nodes = 1u;
+    if (n_tris <= kBig) {                                   // the root goes straight into its class list (parity 0)
+        const int cls = n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : CLS_TINY);
+        hc.cnt[0][cls] = 1u;
+        const uint32_t zero = 0u;
+        HIP_TRY(hipMemcpy(ls.l[0][cls], &zero, 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(d_ctrl, &hc, sizeof hc, hipMemcpyHostToDevice));
     HIP_TRY(hipEventRecord(e0, nullptr));
     hipLaunchKernelGGL(make_proxies, dim3(2048), dim3(256), 0, nullptr, d_tris, n_tris, d_px[0], d_root);
     hipLaunchKernelGGL(init_root, dim3(1), dim3(1), 0, nullptr, d_bn, d_root, n_tris);
     std::vector<uint32_t> lvl_begin;
     uint32_t begin = 0, end = 1;
     int cur = 0;
+    uint32_t parity = 0;
     bool may_have_big = n_tris > kBig;
     std::vector<BNode> hbn;
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
@@ -734,16 +1041,20 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
                 hipLaunchKernelGGL(big_scan, gb, tb, 0, nullptr, d_big, d_chunks, d_cbeg, nb);
                 hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_hp, d_tp);
                 hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp);
-                hipLaunchKernelGGL(big_finish, gb, tb, 0, nullptr, d_big, d_bn, d_cnt, nb);
+                hipLaunchKernelGGL(big_finish, gb, tb, 0, nullptr, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
             }
         }
-        hipLaunchKernelGGL(build_level, dim3(end - begin), dim3(kT), 0, nullptr, d_bn, begin, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_cnt);
-        hipLaunchKernelGGL(build_level_tiny, dim3((end - begin + 255) / 256), dim3(256), 0, nullptr, d_bn, begin, end, d_px[cur], d_px[cur ^ 1], d_cnt);
+        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK], nwav = hc.cnt[parity][CLS_WAVE], ntin = hc.cnt[parity][CLS_TINY];
+        if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kT), 0, nullptr, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
+        if (nwav) hipLaunchKernelGGL(build_level_wave, dim3((nwav + (uint32_t)kWaveNodes - 1u) / (uint32_t)kWaveNodes), dim3(64 * kWaveNodes), 0, nullptr, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, nullptr, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         HIP_TRY(hipGetLastError());
-        uint32_t total = 0;
-        HIP_TRY(hipMemcpy(&total, d_cnt, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));           // also the level's barrier
+        const uint32_t total = hc.n_nodes;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        begin = end; end = total; cur ^= 1;
+        hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = 0u;              // this level's lists are consumed: reset for level + 2
+        HIP_TRY(hipMemcpy(&d_ctrl->cnt[parity][0], &hc.cnt[parity][0], 12, hipMemcpyHostToDevice));
+        begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
     const uint32_t n_nodes = end;
