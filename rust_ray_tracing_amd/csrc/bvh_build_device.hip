@@ -39,11 +39,11 @@ constexpr uint32_t kChunk = 8192;
 constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
 constexpr uint32_t kWaveMax = 512;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
-enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2 };
+enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3 };
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
 // children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
-struct Ctrl { uint32_t n_nodes; uint32_t pad; uint32_t cnt[2][3]; };
-struct Lists { uint32_t *l[2][3]; };
+struct Ctrl { uint32_t n_nodes; uint32_t n_chunks; uint32_t cnt[2][4]; };
+struct Lists { uint32_t *l[2][4]; };
 
 struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
 struct BNode {
@@ -67,7 +67,7 @@ __device__ __forceinline__ float box_area(const float *lo, const float *hi) {   
 // Queue the two children of every active lane for the next level.  One atomic per class per wave: the lanes are ranked
 // with ballots (a per-lane atomicAdd on a per-lane class counter is not aggregated by the compiler and serialises in L2:
 // measured 30x slower on the deep levels).  Works under divergence -- only the lanes that reach this point take part.
-__device__ __forceinline__ uint32_t node_class(uint32_t n) { return n > kBig ? 3u : (n > kWaveMax ? (uint32_t)CLS_BLOCK : (n > kTiny ? (uint32_t)CLS_WAVE : (uint32_t)CLS_TINY)); }
+__device__ __forceinline__ uint32_t node_class(uint32_t n) { return n > kBig ? (uint32_t)CLS_BIG : (n > kWaveMax ? (uint32_t)CLS_BLOCK : (n > kTiny ? (uint32_t)CLS_WAVE : (uint32_t)CLS_TINY)); }
 __device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -77,7 +77,7 @@ __device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint
     const int leader = (int)__ffsll((long long)active) - 1;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (uint32_t c = 0; c < 3u; c++) {                    // class 3 (> kBig) is found by the host on the top levels
+    for (uint32_t c = 0; c < 4u; c++) {
         const unsigned long long ma = __ballot(ca == c), mb = __ballot(cb == c);
         const uint32_t tot = (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
         if (tot == 0u) continue;
@@ -646,20 +646,46 @@ struct BigState {
 };
 struct ChunkInfo { uint32_t big, off, len, hole_cnt, tail_cnt, hole_base, tail_base, pad; };
 
-__global__ void big_init(BigState *bs, const BNode *bn, const uint32_t *ids, uint32_t nb) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nb) return;
-    BigState s;
-    memset(&s, 0, sizeof s);
-    const BNode nd = bn[ids[j]];
-    s.node = ids[j]; s.first = nd.first; s.n = nd.n;
-    for (int a = 0; a < 3; a++) { s.cmin[a] = 0xffffffffu; s.cmax[a] = 0u; s.lo[a] = nd.lo[a]; s.hi[a] = nd.hi[a]; }
-    for (int a = 0; a < 3; a++) for (int k = 0; k < 8; k++) for (int q = 0; q < 6; q++) s.key[a][k][q] = q < 3 ? 0xffffffffu : 0u;
-    for (int sd = 0; sd < 2; sd++) for (int q = 0; q < 6; q++) s.ckey[sd][q] = q < 3 ? 0xffffffffu : 0u;
-    bs[j] = s;
+// One workgroup: a BigState per big node of the level and the chunk table (chunks of a node contiguous, increasing offset),
+// all on the device -- the host only launches (its grids are sized by the bound n_tris / kChunk + nb and the surplus
+// workgroups leave at once).
+__global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, const uint32_t *ids, uint32_t nb, ChunkInfo *ch,
+                                                uint32_t *chunk_begin, Ctrl *ctrl) {
+    __shared__ uint32_t s_warp[4];
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < nb; base += kT) {
+        const uint32_t j = base + threadIdx.x;
+        uint32_t my_chunks = 0;
+        BNode nd;
+        if (j < nb) {
+            nd = bn[ids[j]];
+            BigState s;
+            memset(&s, 0, sizeof s);
+            s.node = ids[j]; s.first = nd.first; s.n = nd.n;
+            for (int a = 0; a < 3; a++) { s.cmin[a] = 0xffffffffu; s.cmax[a] = 0u; s.lo[a] = nd.lo[a]; s.hi[a] = nd.hi[a]; }
+            for (int a = 0; a < 3; a++) for (int k = 0; k < 8; k++) for (int q = 0; q < 6; q++) s.key[a][k][q] = q < 3 ? 0xffffffffu : 0u;
+            for (int sd = 0; sd < 2; sd++) for (int q = 0; q < 6; q++) s.ckey[sd][q] = q < 3 ? 0xffffffffu : 0u;
+            bs[j] = s;
+            my_chunks = (nd.n + kChunk - 1u) / kChunk;
+        }
+        uint32_t tot;
+        const uint32_t off0 = running + block_exscan(my_chunks, s_warp, &tot);
+        if (j < nb) {
+            chunk_begin[j] = off0;
+            for (uint32_t c = 0; c < my_chunks; c++) {
+                ChunkInfo ci;
+                ci.big = j; ci.off = c * kChunk; ci.len = nd.n - ci.off < kChunk ? nd.n - ci.off : kChunk;
+                ci.hole_cnt = ci.tail_cnt = ci.hole_base = ci.tail_base = ci.pad = 0u;
+                ch[off0 + c] = ci;
+            }
+        }
+        running += tot;
+    }
+    if (threadIdx.x == 0) { chunk_begin[nb] = running; ctrl->n_chunks = running; }
 }
-__global__ __launch_bounds__(kT) void big_range(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
+__global__ __launch_bounds__(kT) void big_range(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_mn[3], s_mx[3];
+    if (blockIdx.x >= ctrl->n_chunks) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
@@ -682,11 +708,12 @@ __global__ void big_planes(BigState *bs, uint32_t nb) {
     const float scale = (cmax - cmin) / 8.0f;
     for (int i = 1; i < 8; i++) b->pos[a][i] = cmin + (float)i * scale;
 }
-__global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
+__global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_keyc[kCopies][3][8][6];
     __shared__ uint32_t s_cntc[kCopies][3][8];
     __shared__ float s_pos[3][8];
     __shared__ int s_use[3];
+    if (blockIdx.x >= ctrl->n_chunks) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
@@ -754,8 +781,9 @@ __global__ void big_choose(BigState *bs, uint32_t nb) {                         
     b->k_known = best_k != kNone;
     if (b->k_known) b->k = best_k;
 }
-__global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin) {
+__global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
+    if (blockIdx.x >= ctrl->n_chunks) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     if (!b->split || b->k_known) return;
@@ -767,8 +795,9 @@ __global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *c
     (void)block_exscan(cnt, s_warp, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(&b->k, tot);
 }
-__global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, const Proxy *__restrict__ pin) {   // holes / tail-"<" per chunk
+__global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {   // holes / tail-"<" per chunk
     __shared__ uint32_t s_warp[4];
+    if (blockIdx.x >= ctrl->n_chunks) return;
     ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     if (!b->split) return;
@@ -797,8 +826,10 @@ __global__ void big_scan(BigState *bs, ChunkInfo *ch, const uint32_t *chunk_begi
     acc = 0;
     for (uint32_t c = ce; c-- > cb;) { ch[c].tail_base = acc; acc += ch[c].tail_cnt; }
 }
-__global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, uint32_t *hole_pos, uint32_t *tail_pos) {
+__global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, uint32_t *hole_pos, uint32_t *tail_pos,
+                                               const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
+    if (blockIdx.x >= ctrl->n_chunks) return;
     const ChunkInfo c = ch[blockIdx.x];
     const BigState *b = bs + c.big;
     if (!b->split) return;
@@ -825,9 +856,10 @@ __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkIn
     }
 }
 __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
-                                                  const uint32_t *hole_pos, const uint32_t *tail_pos) {
+                                                  const uint32_t *hole_pos, const uint32_t *tail_pos, const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
     __shared__ uint32_t s_ckey[2][6];
+    if (blockIdx.x >= ctrl->n_chunks) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
@@ -952,7 +984,11 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t sb = nullptr, sw = nullptr, st = nullptr;   // the three per-level kernels touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
+        if (sb) (void)hipStreamDestroy(sb);
+        if (sw) (void)hipStreamDestroy(sw);
+        if (st) (void)hipStreamDestroy(st);
         void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_ids, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (e0) (void)hipEventDestroy(e0);
@@ -973,9 +1009,12 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     // work lists: a level has at most min(2^level, n_tris) nodes; a class list never holds more nodes than triangles / its
     // smallest node... sized by the simple bound n_tris + 1 per (parity, class)
     const size_t list_cap = (size_t)n_tris + 1u;
-    HIP_TRY(hipMalloc((void **)&d_lists, 6 * list_cap * 4));
+    HIP_TRY(hipMalloc((void **)&d_lists, (6 * list_cap + 2 * (size_t)big_cap) * 4));
     Lists ls;
-    for (int pa = 0; pa < 2; pa++) for (int c = 0; c < 3; c++) ls.l[pa][c] = d_lists + (size_t)(pa * 3 + c) * list_cap;
+    for (int pa = 0; pa < 2; pa++) {
+        for (int c = 0; c < 3; c++) ls.l[pa][c] = d_lists + (size_t)(pa * 3 + c) * list_cap;
+        ls.l[pa][CLS_BIG] = d_lists + 6 * list_cap + (size_t)pa * big_cap;
+    }
     HIP_TRY(hipMalloc((void **)&d_root, 24));
     HIP_TRY(hipMalloc((void **)&d_ids, (size_t)big_cap * 4));
     HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
@@ -983,14 +1022,17 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipMalloc((void **)&d_chunks, (size_t)chunk_cap * sizeof(ChunkInfo)));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipStreamCreate(&sb));                          // blocking streams: ordered against the null stream's copies / launches
+    HIP_TRY(hipStreamCreate(&sw));
+    HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
     Ctrl hc;
     memset(&hc, 0, sizeof hc);
     hc.n_nodes = 1u;
-    if (n_tris <= kBig) {                                   // the root goes straight into its class list (parity 0)
-        const int cls = n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : CLS_TINY);
+    {                                                       // the root goes straight into its class list (parity 0)
+        const int cls = n_tris > kBig ? CLS_BIG : (n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : CLS_TINY));
         hc.cnt[0][cls] = 1u;
         const uint32_t zero = 0u;
         HIP_TRY(hipMemcpy(ls.l[0][cls], &zero, 4, hipMemcpyHostToDevice));
@@ -1003,57 +1045,35 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     uint32_t begin = 0, end = 1;
     int cur = 0;
     uint32_t parity = 0;
-    bool may_have_big = n_tris > kBig;
-    std::vector<BNode> hbn;
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
-        if (may_have_big) {                             // top of the tree: nodes too large for one workgroup
-            hbn.resize(end - begin);
-            HIP_TRY(hipMemcpy(hbn.data(), d_bn + begin, (size_t)(end - begin) * sizeof(BNode), hipMemcpyDeviceToHost));
-            std::vector<uint32_t> ids, cbeg;
-            std::vector<ChunkInfo> chunks;
-            for (uint32_t i = 0; i < end - begin; i++) {
-                if (hbn[i].n <= kBig) continue;
-                cbeg.push_back((uint32_t)chunks.size());
-                for (uint32_t off = 0; off < hbn[i].n; off += kChunk) {
-                    ChunkInfo c{};
-                    c.big = (uint32_t)ids.size(); c.off = off; c.len = hbn[i].n - off < kChunk ? hbn[i].n - off : kChunk;
-                    chunks.push_back(c);
-                }
-                ids.push_back(begin + i);
-            }
-            cbeg.push_back((uint32_t)chunks.size());
-            const uint32_t nb = (uint32_t)ids.size(), nc = (uint32_t)chunks.size();
-            if (nb == 0) may_have_big = false;
-            else {
-                if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
-                HIP_TRY(hipMemcpy(d_ids, ids.data(), nb * 4, hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(d_cbeg, cbeg.data(), (nb + 1) * 4, hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(d_chunks, chunks.data(), (size_t)nc * sizeof(ChunkInfo), hipMemcpyHostToDevice));
-                const dim3 gb((nb + 63) / 64), tb(64);
-                hipLaunchKernelGGL(big_init, gb, tb, 0, nullptr, d_big, d_bn, d_ids, nb);
-                hipLaunchKernelGGL(big_range, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
-                hipLaunchKernelGGL(big_planes, dim3((nb * 3 + 63) / 64), tb, 0, nullptr, d_big, nb);
-                hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
-                hipLaunchKernelGGL(big_choose, gb, tb, 0, nullptr, d_big, nb);
-                hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
-                hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur]);
-                hipLaunchKernelGGL(big_scan, gb, tb, 0, nullptr, d_big, d_chunks, d_cbeg, nb);
-                hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_hp, d_tp);
-                hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp);
-                hipLaunchKernelGGL(big_finish, gb, tb, 0, nullptr, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
-            }
+        const uint32_t nb = hc.cnt[parity][CLS_BIG];
+        if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk)
+            const uint32_t nc = n_tris / kChunk + nb;   // bound on sum(ceil(n_j / kChunk)); the real count lives in ctrl->n_chunks
+            if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
+            const dim3 gb((nb + 63) / 64), tb(64);
+            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, nullptr, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl);
+            hipLaunchKernelGGL(big_range, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_planes, dim3((nb * 3 + 63) / 64), tb, 0, nullptr, d_big, nb);
+            hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_choose, gb, tb, 0, nullptr, d_big, nb);
+            hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_scan, gb, tb, 0, nullptr, d_big, d_chunks, d_cbeg, nb);
+            hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_hp, d_tp, d_ctrl);
+            hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
+            hipLaunchKernelGGL(big_finish, gb, tb, 0, nullptr, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
         }
         const uint32_t nblk = hc.cnt[parity][CLS_BLOCK], nwav = hc.cnt[parity][CLS_WAVE], ntin = hc.cnt[parity][CLS_TINY];
-        if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kT), 0, nullptr, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
-        if (nwav) hipLaunchKernelGGL(build_level_wave, dim3((nwav + (uint32_t)kWaveNodes - 1u) / (uint32_t)kWaveNodes), dim3(64 * kWaveNodes), 0, nullptr, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, nullptr, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kT), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
+        if (nwav) hipLaunchKernelGGL(build_level_wave, dim3((nwav + (uint32_t)kWaveNodes - 1u) / (uint32_t)kWaveNodes), dim3(64 * kWaveNodes), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(&hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));           // also the level's barrier
         const uint32_t total = hc.n_nodes;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = 0u;              // this level's lists are consumed: reset for level + 2
-        HIP_TRY(hipMemcpy(&d_ctrl->cnt[parity][0], &hc.cnt[parity][0], 12, hipMemcpyHostToDevice));
+        hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = hc.cnt[parity][3] = 0u;   // this level's lists are consumed: reset for level + 2
+        HIP_TRY(hipMemcpy(&d_ctrl->cnt[parity][0], &hc.cnt[parity][0], 16, hipMemcpyHostToDevice));
         begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
