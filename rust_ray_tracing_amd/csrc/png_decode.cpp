@@ -57,7 +57,8 @@ struct Huff {                       // canonical Huffman decoding table (count/s
     }
 };
 
-bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
+// `limit`: the decoder knows how many bytes the image needs (IHDR); output beyond it is a corrupt or hostile stream
+bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t limit) {
     if (n < 6) return false;
     if ((src[0] & 0x0f) != 8 || ((src[0] << 8 | src[1]) % 31) != 0 || (src[1] & 0x20)) return false;   // zlib header
     BitReader br(src + 2, n - 2);
@@ -74,6 +75,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
             uint32_t len = br.p[br.pos] | br.p[br.pos + 1] << 8, nlen = br.p[br.pos + 2] | br.p[br.pos + 3] << 8;
             br.pos += 4;
             if ((len ^ 0xffff) != nlen || br.pos + len > br.n) return false;
+            if (out.size() + len > limit) return false;
             out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -114,7 +116,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
             for (;;) {
                 int sym = hl.decode(br);
                 if (sym < 0) return false;
-                if (sym < 256) out.push_back((uint8_t)sym);
+                if (sym < 256) { if (out.size() >= limit) return false; out.push_back((uint8_t)sym); }
                 else if (sym == 256) break;
                 else {
                     sym -= 257;
@@ -125,6 +127,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
                     size_t dist = dbase[ds] + br.bits(dext[ds]);
                     if (br.err || dist > out.size()) return false;
                     size_t from = out.size() - dist;
+                    if (out.size() + len > limit) return false;
                     for (size_t i = 0; i < len; i++) out.push_back(out[from + i]);
                 }
             }
@@ -173,9 +176,21 @@ bool decode(const std::string &path, uint32_t *w_out, uint32_t *h_out, std::vect
     const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
                         : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
     if (!channels || !depth_ok) { *err = "unsupported colour type / bit depth"; return false; }
-    std::vector<uint8_t> raw;
-    if (!inflate(idat.data(), idat.size(), raw)) { *err = "zlib stream is corrupt"; return false; }
     const size_t bits = (size_t)channels * depth, bpp = bits >= 8 ? bits / 8 : 1;       // filter unit: whole bytes, at least 1
+    if ((uint64_t)w * h > (1ull << 27)) { *err = "image larger than 2^27 pixels"; return false; }   // same budget as the JPEG path
+    // exact size of the filtered image data (sum over the Adam7 passes): inflate may not produce more, and must produce this
+    static const uint8_t px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+    size_t need = 0;
+    for (int pass = 0; pass < (interlace ? 7 : 1); pass++) {
+        const uint32_t x0 = interlace ? px0[pass] : 0, y0 = interlace ? py0[pass] : 0, dx = interlace ? pdx[pass] : 1, dy = interlace ? pdy[pass] : 1;
+        if (x0 >= w || y0 >= h) continue;
+        const uint32_t pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+        need += (((size_t)pw * bits + 7) / 8 + 1) * ph;
+    }
+    std::vector<uint8_t> raw;
+    raw.reserve(need);
+    if (!inflate(idat.data(), idat.size(), raw, need)) { *err = "zlib stream is corrupt or longer than the image"; return false; }
+    if (raw.size() < need) { *err = "image data too short"; return false; }
     // tRNS colour key for grey / RGB images: a pixel equal to it (at the file's bit depth) becomes transparent
     bool has_key = false;
     uint32_t key[3] = {0, 0, 0};
@@ -187,7 +202,6 @@ bool decode(const std::string &path, uint32_t *w_out, uint32_t *h_out, std::vect
     };
     rgba->assign((size_t)w * h * 4, 255);
     // Adam7: seven reduced images, each filtered on its own; a non-interlaced file is the single pass (0, 0, 1, 1)
-    static const uint8_t px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
     size_t rp = 0;
     std::vector<uint8_t> prev, cur;
     for (int pass = 0; pass < (interlace ? 7 : 1); pass++) {
@@ -254,12 +268,12 @@ bool decode(const std::string &path, uint32_t *w_out, uint32_t *h_out, std::vect
 // "stored" blocks -- a valid PNG without a compressor; rows top first.
 bool write_rgba(const std::string &path, uint32_t w, uint32_t h, int bits, const void *rgba, std::string *err) {
     if (w == 0 || h == 0 || (bits != 8 && bits != 16) || !rgba) { *err = "bad PNG write arguments"; return false; }
-    static uint32_t crc_table[256];
-    static bool have_table = false;
-    if (!have_table) {
-        for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; }
-        have_table = true;
-    }
+    struct CrcTable {                                   // function-local static of class type: initialised once, thread-safely (C++11)
+        uint32_t t[256];
+        CrcTable() { for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1; t[n] = c; } }
+    };
+    static const CrcTable crc_tab;
+    const uint32_t *crc_table = crc_tab.t;
     auto crc = [&](uint32_t c, const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 255u] ^ (c >> 8); return c; };
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) { *err = "cannot create '" + path + "'"; return false; }

@@ -1,8 +1,9 @@
 """CPU, world_size 2 over gloo: the N > 1 path of bench.py -- tile-interleaved pixel shards written
 rank-packed, ONE all-gather, de-interleave -- must reproduce the single-rank frame bit for bit, and the
 sample-sharded sum-reduce (config 5) must equal the rank-ordered sum of the per-rank partials.
-Pixels are produced by the CPU oracle here (no GPU in this container); the HIP kernel's own shard
-outputs are checked against the same index arithmetic in tests/test_gpu_more.py (test_tile_shards_reassemble_bit_exact)."""
+Without a GPU the pixels are produced by the CPU oracle; the -m gpu variant makes every rank render ITS OWN packed tile slice /
+sample-range partial sum with the HIP kernel through the C ABI (both ranks share the box's one GPU) and gathers / reduces
+those over gloo, checking the result against the oracle's whole frame."""
 import os
 import sys
 
@@ -15,7 +16,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, w, h, q):
+def _worker(rank, world, port, w, h, q, use_kernel=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,8 +29,21 @@ def _worker(rank, world, port, w, h, q):
     # --- config 4: tile shards ---
     full, _, _ = orc.render(t, nodes, m, texs, camera, w, h, 2, 8, threads=2)
     pix = sharding.slot_pixels(w, h, rank, world)
-    local = np.zeros((len(pix), 3), dtype=np.float32)
-    local[pix >= 0] = full.reshape(-1, 3)[pix[pix >= 0]]          # what this rank's kernel writes, packed
+    if use_kernel:                                                # this rank's slice from the HIP kernel, rank-packed
+        import ctypes as C
+        import rust_ray_tracing_amd as rrt
+        from rust_ray_tracing_amd import _lib as L
+        sc = rrt.Scene.from_arrays(tris, mats, texs)
+        sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+
+        def kernel(opt, n_floats):
+            out = np.zeros(n_floats, dtype=np.float32)
+            L.check(rrt.load().mipt_render(sc.upload(0), L.ptr(sc.camera.uniform), C.byref(opt), L.ptr(out), None, None), "mipt_render")
+            return out
+        local = kernel(rrt.make_options(w, h, 2, 8, flags=L.FLAG_PACKED, tile_rank=rank, tile_world=world), len(pix) * 3).reshape(-1, 3)
+    else:
+        local = np.zeros((len(pix), 3), dtype=np.float32)
+        local[pix >= 0] = full.reshape(-1, 3)[pix[pix >= 0]]      # what this rank's kernel writes, packed
     gathered = torch.empty(world * local.size, dtype=torch.float32)
     dist.all_gather_into_tensor(gathered, torch.from_numpy(local.reshape(-1)))
     frame = sharding.unpack(gathered.numpy().reshape(world, -1, 3), w, h, world)
@@ -37,7 +51,10 @@ def _worker(rank, world, port, w, h, q):
     # --- config 5: sample shards, per-sample seeds, sum-reduce ---
     spp = 5
     s0, n = sharding.sample_ranges(spp, world)[rank]
-    part, _, _ = orc.render(t, nodes, m, texs, camera, w, h, n, 8, seed_mode=1, sample_begin=s0, sum_only=1, threads=2)
+    if use_kernel:
+        part = kernel(rrt.make_options(w, h, n, 8, seed_mode=L.SEED_PER_SAMPLE, flags=L.FLAG_SUM, sample_begin=s0), w * h * 3).reshape(h, w, 3)
+    else:
+        part, _, _ = orc.render(t, nodes, m, texs, camera, w, h, n, 8, seed_mode=1, sample_begin=s0, sum_only=1, threads=2)
     red = torch.from_numpy(part.copy())
     dist.all_reduce(red)                                          # world 2: a + b is order-independent
     parts = [torch.empty_like(red) for _ in range(world)]
@@ -54,12 +71,11 @@ def _worker(rank, world, port, w, h, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h", [(64, 40), (61, 37)])
-def test_two_rank_tile_gather_and_sample_reduce(built, w, h):
+def _run_two_ranks(w, h, use_kernel):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + w) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + w + (7 if use_kernel else 0)) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, q, use_kernel)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get(timeout=180)
@@ -67,6 +83,17 @@ def test_two_rank_tile_gather_and_sample_reduce(built, w, h):
         p.join(60)
         assert p.exitcode == 0
     assert res == (True, True, True)
+
+
+@pytest.mark.parametrize("w,h", [(64, 40), (61, 37)])
+def test_two_rank_tile_gather_and_sample_reduce(built, w, h):
+    _run_two_ranks(w, h, use_kernel=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(64, 40), (61, 37)])
+def test_two_rank_gather_and_reduce_of_the_kernels_own_shards(built, w, h):
+    _run_two_ranks(w, h, use_kernel=True)
 
 
 def test_slot_layout_is_a_partition():
