@@ -434,3 +434,27 @@ def test_tga_and_bmp_decoders_match_pillow(rrt, tmp_path):
     (tmp_path / "bad.tga").write_bytes(b"\0" * 10)
     (tmp_path / "bad.bmp").write_bytes(b"BM" + b"\0" * 40)
     assert rrt.Texture.load(str(tmp_path / "bad.tga")) is None and rrt.Texture.load(str(tmp_path / "bad.bmp")) is None
+
+
+def test_png_hostile_sizes_are_rejected_before_allocation(rrt, tmp_path):
+    """A ~100-byte PNG must not be able to make the loader allocate gigabytes: dimensions beyond the 2^27-pixel budget and
+    zlib streams that inflate past the size IHDR implies are refused."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    def png(w, h, raw):
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+    huge = tmp_path / "huge.png"
+    huge.write_bytes(png(60000, 60000, b"\0" * 64))
+    assert rrt.Texture.load(str(huge)) is None
+    bomb = tmp_path / "bomb.png"
+    bomb.write_bytes(png(4, 4, b"\0" * (64 << 20)))                    # 64 MiB of zeros compress to ~64 KiB; the image needs 68 bytes
+    assert len(bomb.read_bytes()) < 200_000
+    assert rrt.Texture.load(str(bomb)) is None
+    ok = tmp_path / "ok.png"
+    ok.write_bytes(png(4, 4, b"".join(b"\0" + bytes(range(16 * y, 16 * y + 16)) for y in range(4))))
+    t = rrt.Texture.load(str(ok))
+    assert t is not None and t.width == 4 and t.height == 4
