@@ -143,6 +143,13 @@ def main():
                     help="gloo = rehearsal of the N>1 code path on fewer GPUs than ranks (collectives staged through host memory)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 when a communicator is created (seen from
+    # mipt_render_multi and torch.distributed alike), so fd 1 is pointed at stderr for the whole run and the JSON line is
+    # written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -407,8 +414,9 @@ def main():
             result["parity"]["sample_pixels"] = int(len(idx))
             result["parity"]["rmse"] = float(np.sqrt(np.mean((got.reshape(-1, 3)[idx].astype(np.float64) - hdr_cpu.reshape(-1, 3)[idx]) ** 2)))
 
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,7 +15,9 @@ SMALL = ["--tris", "20000", "--width", "320", "--height", "184", "--spp", "2", "
 def _run(cmd, **kw):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, **kw)
     assert out.returncode == 0, out.stderr[-3000:]
-    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"stdout must be exactly ONE JSON line, got {len(lines)}: {[l[:60] for l in lines]}"
+    return json.loads(lines[0])
 
 
 @pytest.mark.gpu
