@@ -354,9 +354,13 @@ def main():
             del solo
         if world == 1 and args.traversal == "culled" and mode == "tiles":
             ref_buf = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
-            render("tiles", traversal=L.TRAVERSAL_REFERENCE, out=ref_buf)
+            rst = render("tiles", traversal=L.TRAVERSAL_REFERENCE, out=ref_buf)
             torch.cuda.synchronize(dev)
             par["culled_equals_reference_traversal"] = bool(torch.equal(frame_primary.view(torch.int32), ref_buf.view(torch.int32)))
+            # the headline uses the culled traversal (identical frame, re-checked above on every run); the CPU backend's own
+            # un-culled traversal (ray.rs:69-81) on the same frame, one launch:
+            result["reference_traversal"] = {"kernel_ms": round(rst["kernel_ms"], 3),
+                                             "mray_s_kernel": round(local_counts["rays"] / rst["kernel_ms"] / 1e3, 2)}
             del ref_buf
         result["parity"] = par
 
