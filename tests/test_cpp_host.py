@@ -84,6 +84,14 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout + out.stderr[-3000:]
     assert "sanitize_host ok" in out.stdout
+    # and under ThreadSanitizer: mipt_bvh_build splits sub-trees over std::threads and stitches them (bvh_build.cpp)
+    exe_t = str(tmp_path / "sanitize_host_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(src, "bvh_build.cpp"), os.path.join(src, "obj_loader.cpp"), os.path.join(src, "png_decode.cpp"),
+                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(src, "tga_bmp_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe_t, "-lpthread"])
+    out = subprocess.run([exe_t, str(tmp_path), str(tmp_path / "tex.png")] + jpegs, capture_output=True, text=True,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert out.returncode == 0 and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
 
 
 def test_oracle_under_asan_ubsan(built, tmp_path):
@@ -119,9 +127,16 @@ int main(void) {
 }
 ''')
     exe = str(tmp_path / "drv")
-    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
                            "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "oracle"), str(drv), os.path.join(ROOT, "oracle", "pt_oracle.c"),
                            "-o", exe, "-lm", "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr[-3000:]
     assert "oracle asan ok" in out.stdout
+    # the same driver under ThreadSanitizer: the pixel loop shares the scene read-only across its worker threads (the reference's
+    # rayon workers share &Scene, cpu.rs:13,24) and merges per-thread counters under a mutex -- TSan must see no race
+    exe_t = str(tmp_path / "drv_tsan")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "oracle"),
+                           str(drv), os.path.join(ROOT, "oracle", "pt_oracle.c"), "-o", exe_t, "-lm", "-lpthread"])
+    out = subprocess.run([exe_t], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert out.returncode == 0 and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
