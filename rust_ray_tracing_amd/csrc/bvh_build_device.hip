@@ -978,7 +978,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     Proxy *d_px[2] = {nullptr, nullptr};
     BNode *d_bn = nullptr;
     MiptNode *d_nodes = nullptr;
-    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_ids = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
+    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
     Ctrl *d_ctrl = nullptr;
     BigState *d_big = nullptr;
     ChunkInfo *d_chunks = nullptr;
@@ -989,7 +989,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         if (sb) (void)hipStreamDestroy(sb);
         if (sw) (void)hipStreamDestroy(sw);
         if (st) (void)hipStreamDestroy(st);
-        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_ids, d_cbeg, d_big, d_chunks, d_lists};
+        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -1016,7 +1016,6 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         ls.l[pa][CLS_BIG] = d_lists + 6 * list_cap + (size_t)pa * big_cap;
     }
     HIP_TRY(hipMalloc((void **)&d_root, 24));
-    HIP_TRY(hipMalloc((void **)&d_ids, (size_t)big_cap * 4));
     HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
     HIP_TRY(hipMalloc((void **)&d_big, (size_t)big_cap * sizeof(BigState)));
     HIP_TRY(hipMalloc((void **)&d_chunks, (size_t)chunk_cap * sizeof(ChunkInfo)));
