@@ -137,6 +137,30 @@ class Renderer {                                           // src/renderer.rs:8-
         }
         return out;
     }
+
+    // The same arm over EVERY GPU of the node from this single-threaded host (mipt_render_multi: scene replicas, RCCL
+    // communicators and the one gather / sum-reduce per frame live inside the library).  mode = MIPT_MULTI_TILES reproduces
+    // render()'s bytes exactly; MIPT_MULTI_SAMPLES uses the wgpu shader's per-sample seeds (rt_compute.wgsl:102).
+    std::vector<uint8_t> render_node(const Scene &scene, uint32_t mode = MIPT_MULTI_TILES, int n_devices = 0) const {
+        if (options.backend != RendererBackend::MI355X) { log_error("this build only provides RendererBackend::MI355X"); return {}; }
+        std::vector<MiptMaterial> mats;
+        for (const auto &kv : scene.materials) mats.push_back(kv.second);
+        std::vector<MiptTexture> texs;
+        for (const Texture &t : scene.textures) texs.push_back({t.width, t.height, t.pixel_data.data()});
+        MiptSceneDesc d{scene.tris.data(), (uint32_t)scene.tris.size(), scene.bvh_nodes.data(), (uint32_t)scene.bvh_nodes.size(),
+                        mats.data(), (uint32_t)mats.size(), texs.data(), (uint32_t)texs.size()};
+        MiptMulti *m = nullptr;
+        if (mipt_multi_create(&d, nullptr, n_devices, &m) != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        MiptOptions o{};
+        o.width = (uint32_t)options.output_image_dimensions.first; o.height = (uint32_t)options.output_image_dimensions.second;
+        o.samples = (uint32_t)options.samples; o.max_ray_depth = (uint32_t)options.max_ray_depth;
+        o.traversal = options.traversal; o.cull_margin = MIPT_CULL_MARGIN_SAFE;
+        std::vector<uint8_t> out((size_t)o.width * o.height * 4);
+        const int rc = mipt_render_multi(m, &scene.camera.uniform, &o, mode, nullptr, out.data(), nullptr);
+        mipt_multi_destroy(m);
+        if (rc != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        return out;
+    }
 };
 
 } // namespace mipt

@@ -57,6 +57,8 @@ int main(int argc, char **argv) {
     std::ifstream f(argv[3], std::ios::binary);
     std::vector<uint8_t> want((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     CHECK(want.size() == px.size() && memcmp(want.data(), px.data(), px.size()) == 0);
+    const std::vector<uint8_t> px_node = r->render_node(*scene);                     // all GPUs of the node, one call (RCCL inside)
+    CHECK(px_node.size() == px.size() && memcmp(px_node.data(), px.data(), px.size()) == 0);
     printf("host mirror (gpu) ok: config 1 RGBA8 identical to the oracle\n");
     return 0;
 }
