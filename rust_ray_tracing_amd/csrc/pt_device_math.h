@@ -50,6 +50,7 @@ __device__ __forceinline__ float rand_f32(uint32_t &s) { return (float)xor_shift
 // Pinned: tests/test_libm_pin.py (CPU restatement == the machine's libm on every binary32 of the path's domains) and
 // tests/test_gpu_libm.py (these device functions == the CPU restatement on the same sweeps).
 #define GLIBC_FLT32_TABLE static __device__ const
+#define GLIBC_FLT32_CONST static constexpr            // read at constant indices only: every coefficient folds into an immediate
 #include "glibc_flt32_data.h"
 
 __device__ __forceinline__ double gl_d(const uint64_t *t, int i) { return __longlong_as_double((long long)t[i]); }
