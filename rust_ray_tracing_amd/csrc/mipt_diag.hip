@@ -39,6 +39,8 @@ __global__ void debug_eval_kernel(int op, const float *__restrict__ a, const flo
         case 16: r = gl_sinf(x); break;
         case 17: r = gl_expf(x); break;
         case 18: r = gl_logf(x, GlTabGlobal()); break;
+        case 19: r = gl_log10f_unit(x, GlTabGlobal()); break;                              // valid on {0} u [2^-32, 1]
+        case 20: r = gl_cosf_2pi(x); break;                                                // valid on [0, 6.2831855]
         default: break;
         }
         out[i] = r;
@@ -59,6 +61,8 @@ __global__ void debug_eval_range_kernel(int op, uint32_t first_bits, float y, un
         case 16: r = gl_sinf(x); break;
         case 17: r = gl_expf(x); break;
         case 18: r = gl_logf(x, GlTabGlobal()); break;
+        case 19: r = gl_log10f_unit(x, GlTabGlobal()); break;
+        case 20: r = gl_cosf_2pi(x); break;
         default: break;
         }
         out[i] = r;

@@ -301,12 +301,62 @@ __device__ __forceinline__ float gl_expf(float x) {
     return (float)y;
 }
 
+// ---- the two libm calls of the scatter step, specialised to the arguments rand_f32 can produce -------------------------
+// rand_f32 (math.rs:22-24) returns RN(k) / 2^32 for a 32-bit k: exactly 0, or a value in [2^-32, 1] -- never negative,
+// subnormal, infinite or NaN.  On that domain gl_log10f / gl_cosf reduce to straight-line code (the general functions spend
+// a third of their instructions on exec-mask scaffolding for cases that cannot occur here, inside the service pass where
+// only ~15 lanes of the wave are active).  Same operations in the same order on every reachable argument, so the results
+// are the general functions' bits; tests/test_gpu_libm.py sweeps EVERY binary32 of both domains against the CPU restatement.
+//
+// log10f on {0} u [2^-32, 1]: x normal and positive, so e_log10f.c's k = exponent, i = (k < 0), x' = mantissa * 2^-i in [0.5, 2)
+// and e_logf.c runs without its special-case block; logf(1.0f) is the explicit `return 0` of e_logf.c:40.
+template <class TabPtr>
+__device__ __forceinline__ float gl_log10f_unit(float x, TabPtr tab) {
+    const float log10_2lo = __uint_as_float(glibc_log10f_consts[1]), ivln10 = __uint_as_float(glibc_log10f_consts[2]);
+    const float log10_2hi = __uint_as_float(glibc_log10f_consts[3]);
+    const int hx = (int)__float_as_uint(x);
+    const int k = (hx >> 23) - 127;
+    const int i = (int)((uint32_t)k >> 31);
+    const uint32_t ix = ((uint32_t)hx & 0x007fffffu) | ((uint32_t)(0x7f - i) << 23);
+    const float y = (float)(k + i);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t j = (tmp >> 19) & 15u;
+    const int kk = (int)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = tab[2 * j], logc = tab[2 * j + 1];
+    const double z = (double)__uint_as_float(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = __builtin_fma((double)kk, gl_d(glibc_logf_ln2, 0), logc);
+    const double r2 = r * r;
+    double p = __builtin_fma(gl_d(glibc_logf_poly, 1), r, gl_d(glibc_logf_poly, 2));
+    p = __builtin_fma(gl_d(glibc_logf_poly, 0), r2, p);
+    p = __builtin_fma(p, r2, y0 + r);
+    const float lg = (ix == 0x3f800000u) ? 0.0f : (float)p;          // e_logf.c: logf(1) = 0 exactly
+    const float zf = y * log10_2lo + ivln10 * lg;
+    const float res = zf + y * log10_2hi;
+    return (hx == 0) ? -__builtin_inff() : res;                       // e_log10f.c: log10(+0) = -two25 / 0 = -inf
+}
+// cosf on [0, 6.2831855] (theta = 6.283185f * rand_f32): below pi/4 reduce_fast gives n = 0 and leaves x untouched
+// (fma(-0, hpi, x) = x), so s_cosf.c's small-argument branch and its reduce_fast branch are the same arithmetic; below
+// 2^-12 the cosine polynomial itself rounds to 1.0f, which is what s_cosf.c returns there.  Both polynomials are evaluated
+// and one is selected (the quadrant is random: a branch would run both sides anyway).
+__device__ __forceinline__ float gl_cosf_2pi(float y) {
+    int n;
+    const double x = gl_reduce_fast((double)y, &n);
+    const double x2 = x * x;
+    const double s = ((n + 1) & 2) ? -1.0 : 1.0;                      // sign[n & 3] = {1, -1, -1, 1}
+    const double sn = gl_sin_poly(x * s, x2);
+    double cs = gl_cos_poly(x2);
+    if (n & 2) cs = -cs;                                              // __sincosf_table[1]
+    return (float)(((n ^ 1) & 1) ? cs : sn);
+}
+
 // math.rs:15-19 (log10, not ln: SURVEY T3)
 template <class TabPtr>
 __device__ __forceinline__ float rand_f32_nd(uint32_t &s, TabPtr logtab) {
     float theta = 6.283185f * rand_f32(s);
-    float rho = __builtin_sqrtf(-2.0f * gl_log10f(rand_f32(s), logtab));
-    return rho * gl_cosf(theta);
+    float rho = __builtin_sqrtf(-2.0f * gl_log10f_unit(rand_f32(s), logtab));
+    return rho * gl_cosf_2pi(theta);
 }
 // vec3.rs:66-68 -- x, y, z drawn in that order
 template <class TabPtr>

@@ -15,7 +15,7 @@ def _bits(x):
     return int(np.float32(x).view(np.uint32))
 
 
-def _sweep(rrt, orc, op, first, last, y=0.0):
+def _sweep(rrt, orc, op, first, last, y=0.0, ref_op=None):
     diag = rrt.load_diag()
     bad = 0
     examples = []
@@ -25,7 +25,8 @@ def _sweep(rrt, orc, op, first, last, y=0.0):
         dev = np.empty(n, dtype=np.float32)
         assert diag.mipt_debug_eval_range(op, b, n, float(y), dev.ctypes.data) == 0, diag.mipt_diag_last_error()
         x = np.arange(b, b + n, dtype=np.uint64).astype(np.uint32).view(np.float32)
-        ref = orc.eval_array(op, x, None if op != 2 else np.float32(y), libm=orc.LIBM_GLIBC235, threads=16)
+        rop = op if ref_op is None else ref_op
+        ref = orc.eval_array(rop, x, None if rop != 2 else np.float32(y), libm=orc.LIBM_GLIBC235, threads=16)
         d, r = dev.view(np.uint32), ref.view(np.uint32)
         neq = (d != r) & ~(np.isnan(dev) & np.isnan(ref))
         k = int(np.count_nonzero(neq))
@@ -58,3 +59,13 @@ def test_device_sinf_expf_powf22_on_the_wgpu_shading_domains(rrt, orc):
     assert _sweep(rrt, orc, 16, 0, _bits(6.2831855)) == (0, [])
     assert _sweep(rrt, orc, 17, _bits(-0.0), _bits(-128.0)) == (0, [])
     assert _sweep(rrt, orc, 2, 0, _bits(1.0), 2.2) == (0, [])
+
+
+def test_the_kernels_specialised_log10f_and_cosf_equal_the_general_functions_on_their_whole_domain(rrt, orc):
+    """The scatter step (math.rs:15-19) calls gl_log10f_unit / gl_cosf_2pi -- straight-line forms valid on what rand_f32 can
+    produce: log10 of {0} u [2^-32, 1], cos of 6.283185f * r in [0, 6.2831855].  EVERY binary32 of both domains must give the
+    bits of the CPU restatement of glibc's log10f / cosf (ops 19 / 20 of the probe vs ops 1 / 0 of the oracle)."""
+    top = _bits(np.float32(6.283185) * np.float32(1.0))
+    assert _sweep(rrt, orc, 20, 0, top, ref_op=0) == (0, [])
+    assert _sweep(rrt, orc, 19, 0, 0, ref_op=1) == (0, [])                             # log10(0) = -inf
+    assert _sweep(rrt, orc, 19, _bits(2.0 ** -32), _bits(1.0), ref_op=1) == (0, [])
