@@ -13,6 +13,7 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(MiptVec3) == 12, "Vec3f");
@@ -122,9 +123,11 @@ void mipt_material_default(MiptMaterial *m) {        // scene.rs:148-167
         m->emission_tex_id = m->normal_tex_id = UINT32_MAX;
 }
 
-static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
-    if (!desc || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
-    *out = nullptr;
+// Builds the device layout ONCE on the host and uploads it to every device of `device_ids` (replicas for mipt_multi_create are
+// uploaded concurrently, one host thread per device: each upload is bound by its own PCIe link).
+static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
+    if (!desc || !outs || !device_ids || n_dev < 1) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
+    for (int i = 0; i < n_dev; i++) outs[i] = nullptr;
     if (!desc->tris || desc->n_tris == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no triangles (the reference panics in BVH::build)");
     if (!desc->nodes || desc->n_nodes == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no BVH nodes");
     if (!desc->materials || desc->n_materials == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no materials");
@@ -302,25 +305,6 @@ static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene
     for (uint32_t i = 0; i < desc->n_textures; i++)
         memcpy(texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
 
-    // ---- device ----
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device_id < 0 || device_id >= ndev) return fail(MIPT_ERR_HIP, "HIP device %d not available (%d visible)", device_id, ndev);
-    HIP_TRY(hipSetDevice(device_id));
-    MiptScene *s = new (std::nothrow) MiptScene();
-    if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
-    s->device = device_id;
-    s->max_leaf = max_leaf;
-    int rc;
-    // pairs and tri_pos share one allocation (one buffer descriptor, 32-bit offsets in the kernel)
-    const size_t pairs_bytes = pairs.size() * sizeof(float4), pos_bytes = tri_pos.size() * sizeof(float4);
-    if (pairs_bytes + pos_bytes >= 0xffffffffull) { free_scene(s); return fail(MIPT_ERR_SCENE_LIMIT, "BVH + triangle stream exceed 4 GiB"); }
-    {
-        hipError_t e1 = hipMalloc(&s->d_geom, pairs_bytes + pos_bytes + 64);
-        if (e1 == hipSuccess && pairs_bytes) e1 = hipMemcpy(s->d_geom, pairs.data(), pairs_bytes, hipMemcpyHostToDevice);
-        if (e1 == hipSuccess) e1 = hipMemcpy((char *)s->d_geom + pairs_bytes, tri_pos.data(), pos_bytes, hipMemcpyHostToDevice);
-        if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
-    }
     // tree top in BFS order for the LDS staging experiment: pair k's children that are cached get (kTopFlag | slot)
     std::vector<float4> top;
     uint32_t n_top = 0;
@@ -351,6 +335,30 @@ static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene
             }
         }
     }
+    if (desc->nodes[0].num_tris == 0 && desc->nodes[0].first_tri_or_child != 1u)
+        return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)");
+    // pairs and tri_pos share one allocation (one buffer descriptor, 32-bit offsets in the kernel)
+    const size_t pairs_bytes = pairs.size() * sizeof(float4), pos_bytes = tri_pos.size() * sizeof(float4);
+    if (pairs_bytes + pos_bytes >= 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "BVH + triangle stream exceed 4 GiB");
+
+    // ---- device(s) ----
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    for (int i = 0; i < n_dev; i++)
+        if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(MIPT_ERR_HIP, "HIP device %d not available (%d visible)", device_ids[i], ndev);
+    auto upload_to = [&](int device_id, MiptScene **out) -> int {
+    HIP_TRY(hipSetDevice(device_id));
+    MiptScene *s = new (std::nothrow) MiptScene();
+    if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
+    s->device = device_id;
+    s->max_leaf = max_leaf;
+    int rc;
+    {
+        hipError_t e1 = hipMalloc(&s->d_geom, pairs_bytes + pos_bytes + 64);
+        if (e1 == hipSuccess && pairs_bytes) e1 = hipMemcpy(s->d_geom, pairs.data(), pairs_bytes, hipMemcpyHostToDevice);
+        if (e1 == hipSuccess) e1 = hipMemcpy((char *)s->d_geom + pairs_bytes, tri_pos.data(), pos_bytes, hipMemcpyHostToDevice);
+        if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
+    }
     if ((rc = upload(&s->d_top, top, 64)) || (rc = upload(&s->d_tri_attr, tri_attr)) ||
         (rc = upload(&s->d_mats, mats, 64)) || (rc = upload(&s->d_mats_full, mats_full, 128)) || (rc = upload(&s->d_texels, texels, 16))) {
         free_scene(s);
@@ -379,12 +387,31 @@ static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene
     // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0
     s->dev.root_a = desc->nodes[0].num_tris > 0 ? desc->nodes[0].first_tri_or_child : 0u;
     s->dev.root_n = desc->nodes[0].num_tris;
-    if (desc->nodes[0].num_tris == 0 && desc->nodes[0].first_tri_or_child != 1u) {
-        free_scene(s);
-        return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)");
-    }
     *out = s;
     return MIPT_OK;
+    };
+    if (n_dev == 1) return upload_to(device_ids[0], &outs[0]);
+    std::vector<int> rcs((size_t)n_dev, 0);
+    std::vector<std::string> errs((size_t)n_dev);
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_dev; i++)
+            th.emplace_back([&, i] { rcs[(size_t)i] = upload_to(device_ids[i], &outs[i]); if (rcs[(size_t)i]) errs[(size_t)i] = g_err; });
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < n_dev; i++)
+        if (rcs[(size_t)i]) {
+            const int rc = rcs[(size_t)i];
+            const std::string msg = "device " + std::to_string(device_ids[i]) + ": " + errs[(size_t)i];
+            for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
+            return fail(rc, "%s", msg.c_str());
+        }
+    return MIPT_OK;
+}
+static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
+    if (!out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
+    *out = nullptr;
+    return scene_create_many(desc, &device_id, 1, out);
 }
 
 // No C++ exception may cross the C ABI (the caller may be Rust or C): allocation failures become status codes.
@@ -393,6 +420,10 @@ static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene
     catch (const std::bad_alloc &) { return fail(MIPT_ERR_INVALID_ARG, "out of host memory"); }                        \
     catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, "internal error: %s", e.what()); }
 int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out) { MIPT_NO_THROW(scene_create_impl(desc, device_id, out)) }
+// internal (mipt_multi.cpp): one host-side layout build, n uploads
+int mipt_scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
+    MIPT_NO_THROW(scene_create_many(desc, device_ids, n_dev, outs))
+}
 
 void mipt_scene_destroy(MiptScene *scene) { free_scene(scene); }
 

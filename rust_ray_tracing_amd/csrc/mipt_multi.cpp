@@ -24,6 +24,7 @@
 #include <vector>
 
 void mipt_internal_set_error(const char *msg);
+extern "C" int mipt_scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs);
 extern "C" int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt, float *d_hdr_rgb,
                                        uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single);
 
@@ -110,20 +111,11 @@ int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices,
     m->streams.assign(n_devices, nullptr);
     m->d_part.assign(n_devices, nullptr);
     m->part_floats.assign(n_devices, 0);
-    // scene replicas: uploads run concurrently, one host thread per device (each upload is PCIe-bound on its own link)
-    std::vector<int> rcs(n_devices, 0);
-    std::vector<std::string> errs(n_devices);
+    // scene replicas: the device layout is built once on the host, the uploads run concurrently (one host thread per device)
     {
-        std::vector<std::thread> th;
-        for (int i = 0; i < n_devices; i++)
-            th.emplace_back([&, i] {
-                rcs[i] = mipt_scene_create(desc, m->devices[i], &m->scenes[i]);
-                if (rcs[i]) errs[i] = mipt_last_error();
-            });
-        for (auto &t : th) t.join();
+        const int rc = mipt_scene_create_replicas(desc, m->devices.data(), n_devices, m->scenes.data());
+        if (rc) { const std::string e = mipt_last_error(); destroy(m); return fail(rc, e); }
     }
-    for (int i = 0; i < n_devices; i++)
-        if (rcs[i]) { const int rc = rcs[i]; const std::string e = errs[i]; destroy(m); return fail(rc, "device " + std::to_string(i) + ": " + e); }
     for (int i = 0; i < n_devices; i++) {
         hipError_t e = hipSetDevice(m->devices[i]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking);
