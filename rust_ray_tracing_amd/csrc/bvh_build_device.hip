@@ -979,7 +979,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     BNode *d_bn = nullptr;
     MiptNode *d_nodes = nullptr;
     uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
-    Ctrl *d_ctrl = nullptr;
+    Ctrl *d_ctrl = nullptr, *h_ctrl = nullptr;
     BigState *d_big = nullptr;
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
@@ -991,6 +991,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         if (st) (void)hipStreamDestroy(st);
         void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
+        if (h_ctrl) (void)hipHostFree(h_ctrl);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
@@ -1006,6 +1007,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipMalloc((void **)&d_hp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_ctrl, sizeof(Ctrl)));
+    HIP_TRY(hipHostMalloc((void **)&h_ctrl, sizeof(Ctrl), hipHostMallocDefault));
     // work lists: a level has at most min(2^level, n_tris) nodes; a class list never holds more nodes than triangles / its
     // smallest node... sized by the simple bound n_tris + 1 per (parity, class)
     const size_t list_cap = (size_t)n_tris + 1u;
@@ -1068,11 +1070,12 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         if (nwav) hipLaunchKernelGGL(build_level_wave, dim3((nwav + (uint32_t)kWaveNodes - 1u) / (uint32_t)kWaveNodes), dim3(64 * kWaveNodes), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(&hc, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));           // also the level's barrier
+        HIP_TRY(hipMemcpy(h_ctrl, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));        // pinned target; also the level's barrier
+        hc = *h_ctrl;
         const uint32_t total = hc.n_nodes;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
         hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = hc.cnt[parity][3] = 0u;   // this level's lists are consumed: reset for level + 2
-        HIP_TRY(hipMemcpy(&d_ctrl->cnt[parity][0], &hc.cnt[parity][0], 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, 16, nullptr));           // stream-ordered, no host round trip
         begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
