@@ -170,74 +170,6 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             pairs[(size_t)k * 4 + w * 2 + 1] = hi;
         }
     }
-#if defined(MIPT_PAIR_LAYOUT) && MIPT_PAIR_LAYOUT != 0
-    // Layout experiments (tools/ab.py): the order of the 64-B pair records in HBM is free (topology and visit order are not).
-    //   1: breadth-first, a node's two child pairs adjacent AND in one 128-B line (the memory side fetches whole 128-B lines:
-    //      profiles/r2_fetch_calibration.csv), couples first in every level, one pad record where a level would start odd
-    //   2: depth-first as the reference, but every pair shares its 128-B line with its larger child pair where possible
-    if (n_pairs > 0) {
-        std::vector<uint32_t> order;                       // new index -> old pair index (0xffffffff = pad)
-        order.reserve((size_t)n_pairs + 64);
-        auto child_pair = [&](uint32_t k, uint32_t w, uint32_t *out) -> bool {
-            uint32_t a, n;
-            memcpy(&a, &pairs[(size_t)k * 4 + w * 2].w, 4); memcpy(&n, &pairs[(size_t)k * 4 + w * 2 + 1].w, 4);
-            if (n != 0u) return false;
-            *out = a;
-            return true;
-        };
-#if MIPT_PAIR_LAYOUT == 1
-        std::vector<uint32_t> level{0u}, next;
-        while (!level.empty()) {
-            if (order.size() & 1u) order.push_back(0xffffffffu);           // levels start line-aligned
-            std::vector<uint32_t> couples, singles;
-            for (uint32_t k : level) order.push_back(k);
-            for (uint32_t k : level) {
-                uint32_t ca = 0, cb = 0;
-                const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
-                if (ha && hb) { couples.push_back(ca); couples.push_back(cb); }
-                else if (ha) singles.push_back(ca);
-                else if (hb) singles.push_back(cb);
-            }
-            next = couples;
-            next.insert(next.end(), singles.begin(), singles.end());
-            level.swap(next);
-        }
-#else
-        // depth-first with line mates: emit(P) places P; if P sits at an even slot its heavier inner child follows at once
-        // (same line), then the subtrees in the reference's order
-        std::vector<uint32_t> sub(n_pairs, 1u);                            // subtree sizes in pairs (children have larger indices)
-        for (uint32_t k = n_pairs; k-- > 0;) { uint32_t c; for (uint32_t w = 0; w < 2; w++) if (child_pair(k, w, &c)) sub[k] += sub[c]; }
-        std::vector<uint8_t> placed(n_pairs, 0);
-        std::vector<uint32_t> stack{0u};
-        while (!stack.empty()) {
-            const uint32_t k = stack.back(); stack.pop_back();
-            const bool just = !placed[k];
-            if (just) { order.push_back(k); placed[k] = 1; }
-            uint32_t ca = 0, cb = 0;
-            const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
-            if (just && (order.size() & 1u) && (ha || hb)) {                        // k sits at an even slot: its line has one free half
-                const uint32_t mate = (ha && hb) ? (sub[ca] >= sub[cb] ? ca : cb) : (ha ? ca : cb);
-                if (!placed[mate]) { order.push_back(mate); placed[mate] = 1; }
-            }
-            if (hb) stack.push_back(cb);
-            if (ha) stack.push_back(ca);
-        }
-#endif
-        std::vector<uint32_t> new_of(n_pairs, 0u);
-        for (size_t j = 0; j < order.size(); j++) if (order[j] != 0xffffffffu) new_of[order[j]] = (uint32_t)j;
-        if (new_of[0] != 0u || order.size() > (size_t)mipt::kMaxPairs) return fail(MIPT_ERR_SCENE_LIMIT, "pair layout experiment: bad order");
-        std::vector<float4> re(order.size() * 4, make_float4(0, 0, 0, 0));
-        for (size_t j = 0; j < order.size(); j++) {
-            if (order[j] == 0xffffffffu) continue;
-            for (int q = 0; q < 4; q++) re[j * 4 + q] = pairs[(size_t)order[j] * 4 + q];
-            for (uint32_t w = 0; w < 2; w++) {
-                uint32_t c;
-                if (child_pair(order[j], w, &c)) { const uint32_t nc = new_of[c]; memcpy(&re[j * 4 + w * 2].w, &nc, 4); }
-            }
-        }
-        pairs.swap(re);
-    }
-#endif
     // ---- triangles: 48-B intersection stream + 64-B shading stream ----
     std::vector<float4> tri_pos((size_t)desc->n_tris * 3 + 1);   // +1: the kernel's unconditional 4th float4 load
     std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
