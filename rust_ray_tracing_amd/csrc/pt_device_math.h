@@ -392,13 +392,7 @@ __device__ __forceinline__ uint32_t srgb_quantize(float c) {
 // tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
 __device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
     const float q0 = a * r;
-#if defined(MIPT_WHATIF_FDIV) && MIPT_WHATIF_FDIV == 2      // timing experiment only (wrong results): no correction
-    return q0;
-#endif
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
-#if defined(MIPT_WHATIF_FDIV) && MIPT_WHATIF_FDIV == 1      // timing experiment only: one correction
-    return q1;
-#endif
     return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
 }
 // u8 -> f32 / 255.0 (vec3.rs:252-260) with the same exact two-correction quotient as fdiv_ray: the numerator is an

@@ -522,22 +522,11 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SI
                 const float4 *q = s_top + (pair & 0xffffu) * 4u;
                 r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3];
             } else {
-#if defined(MIPT_WHATIF_LOADS) && MIPT_WHATIF_LOADS == 2       // timing experiment only (wrong results): half the load instructions
-                r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = r0; r3 = r1;
-                r2.w = r0.w; r3.w = r1.w;
-#else
                 r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
                 r3 = ldg4(geom, voff + 48u);                             // tri_pos is padded by one float4
-#endif
             }
             // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
             // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
-#ifdef MIPT_WHATIF_EXTRA_LOADS                                  // timing experiment only: re-load quarters of the SAME record (same lines)
-            {
-                float4 x0 = ldg4(geom, voff), x1 = ldg4(geom, voff + 32u);
-                asm volatile("" :: "v"(x0.x), "v"(x1.x));
-            }
-#endif
             asm volatile("" ::: "memory");
             if (COUNT && DIAG_STAMPS) {      // diagnostic only: split an iteration into memory wait and the rest
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -568,14 +557,6 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SI
                 const float max_d = best_t * pr.cull_scale;
                 float d1, d2;
                 slab_pair<CULL>(o, d, rd, dir_safe, r0, r1, r2, r3, max_d, d1, d2);
-#ifdef MIPT_WHATIF_EXTRA_VALU                                   // timing experiment only: N extra dependent FMAs per inner step
-                {
-                    float dummy = r0.x;
-#pragma unroll
-                    for (int k = 0; k < MIPT_WHATIF_EXTRA_VALU; k++) dummy = __builtin_fmaf(dummy, 1.0001f, o.x);
-                    if (dummy == 123.456f) d1 = d2;
-                }
-#endif
                 uint32_t a1 = __float_as_uint(r0.w), n1 = __float_as_uint(r1.w);
                 uint32_t a2 = __float_as_uint(r2.w), n2 = __float_as_uint(r3.w);
                 uint32_t w2 = 1u;
