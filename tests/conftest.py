@@ -12,6 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A bare `pytest` in a container without a GPU must pass: tests marked `gpu` are skipped there (they are the parity tests
+    proper and run with `-m gpu` on an MI355X; nothing here falls back to a CPU renderer)."""
+    if not any("gpu" in it.keywords for it in items):
+        return
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no HIP device visible here)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def built():
     """Build libmipt.so and the oracle once per session (hipcc cross-compiles without a GPU)."""
