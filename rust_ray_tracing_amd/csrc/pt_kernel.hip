@@ -308,11 +308,14 @@ __device__ __forceinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 
 #ifndef MIPT_MIN_WAVES_PER_SIMD
 #define MIPT_MIN_WAVES_PER_SIMD 5      // CPU-backend shading: 96 VGPRs, no scratch (97 without the bound = 4 waves)
 #endif
+#ifndef MIPT_MIN_WAVES_UNCULLED
+#define MIPT_MIN_WAVES_UNCULLED 4      // the CPU backend's un-culled traversal: squeezed into 96 VGPRs it runs 169 ms, at its natural 98 (4 waves) 143 ms
+#endif
 #ifndef MIPT_MIN_WAVES_SHADING1
 #define MIPT_MIN_WAVES_SHADING1 4      // wgpu-shader shading, fully inlined: 128 VGPRs + 56 B scratch (146 without the bound = 3 waves)
 #endif
 template <bool COUNT, bool CULL, bool LDS_TOP, int SHADING>
-__global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? MIPT_MIN_WAVES_PER_SIMD : MIPT_MIN_WAVES_SHADING1) void pt_trace_kernel(DevScene sc, DevParams pr) {
+__global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? MIPT_MIN_WAVES_PER_SIMD : MIPT_MIN_WAVES_UNCULLED) : MIPT_MIN_WAVES_SHADING1) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];   // row kStackLds: scratch target of the branch-free push
     __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
     __shared__ double s_logtab[32];                                    // __logf_data.tab (16 x {invc, logc}) for gl_log10f

@@ -20,6 +20,7 @@ ap.add_argument("--spp", type=int, default=8)
 ap.add_argument("--world", type=int, default=1, help="render only rank 0's tile share of this many ranks")
 ap.add_argument("--shading", type=int, default=0)
 ap.add_argument("--depth", type=int, default=64)
+ap.add_argument("--traversal", type=int, default=1, help="0 = the CPU backend's un-culled traversal, 1 = culled (margin 2^-7)")
 ap.add_argument("--count", action="store_true", help="one extra counting launch: rays / inner steps / tri tests")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
@@ -45,7 +46,7 @@ for path in args.libs:
     assert rc == 0, lib.mipt_last_error()
     ts = []
     for rep in range(args.reps):
-        o = rrt.make_options(w, h, args.spp, args.depth, traversal=1, flags=L.FLAG_PACKED if args.world > 1 else 0, tile_rank=0,
+        o = rrt.make_options(w, h, args.spp, args.depth, traversal=args.traversal, flags=L.FLAG_PACKED if args.world > 1 else 0, tile_rank=0,
                              tile_world=args.world, shading=args.shading)
         st = L.MiptStats()
         rc = lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st))
@@ -53,7 +54,7 @@ for path in args.libs:
         ts.append(st.kernel_ms)
     extra = ""
     if args.count:
-        o = rrt.make_options(w, h, args.spp, args.depth, traversal=1, flags=L.FLAG_COUNT | (L.FLAG_PACKED if args.world > 1 else 0), tile_rank=0,
+        o = rrt.make_options(w, h, args.spp, args.depth, traversal=args.traversal, flags=L.FLAG_COUNT | (L.FLAG_PACKED if args.world > 1 else 0), tile_rank=0,
                              tile_world=args.world, shading=args.shading)
         st = L.MiptStats()
         assert lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st)) == 0
