@@ -139,14 +139,19 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
 
     // ---- validate and re-base the BVH: pair[k] = {nodes[2k+1], nodes[2k+2]} ----
     uint32_t max_leaf = 0;
+    uint32_t tiny_axes = 0;
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const MiptNode &n = desc->nodes[i];
-        {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (pt_kernel.hip ray_safe)
-            const float lim = 1.0995116e12f;
+        {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused); axes on which some
+            // plane coordinate is tiny but not 0 are flagged, and a ray starting at exactly 0 on such an axis divides the IEEE way
+            // (pt_kernel.hip ray_safe)
+            const float lim = 1.0995116e12f, tiny = 1.3234890e-23f /* 2^-76 */;
             const float *b = &n.bounds_min.x, *c = &n.bounds_max.x;
-            for (int k = 0; k < 3; k++)
+            for (int k = 0; k < 3; k++) {
                 if (!(fabsf(b[k]) <= lim) || !(fabsf(c[k]) <= lim))
                     return fail(MIPT_ERR_SCENE_LIMIT, "node %u has a non-finite bound or one beyond 2^40", i);
+                if ((b[k] != 0.0f && fabsf(b[k]) < tiny) || (c[k] != 0.0f && fabsf(c[k]) < tiny)) tiny_axes |= 1u << k;
+            }
         }
         if (n.num_tris > 0) {
             if ((uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris)
@@ -311,6 +316,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     s->dev.geom_bytes = (uint32_t)(pairs_bytes + pos_bytes);
     s->dev.top = (const float4 *)s->d_top;
     s->dev.n_top = n_top;
+    s->dev.tiny_axes = tiny_axes;
     s->dev.tri_attr = (const float4 *)s->d_tri_attr;
     s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
     s->dev.mats_full = (const mipt::DevMaterialFull *)s->d_mats_full;

@@ -385,11 +385,11 @@ __device__ __forceinline__ uint32_t srgb_quantize(float c) {
 // FMAs, mul, 3 residual FMAs, div_fmas, div_fixup).  Everything that depends only on d is hoisted to once per ray:
 // r = RN(1/d); per quotient the same quotient refinement the hardware sequence ends with remains --
 //   q0 = a*r; q1 = q0 + (a - q0*d)*r; q2 = q1 + (a - q1*d)*r      (residuals exact in FMA)
-// q1 is faithful, q2 = RN(a/d) (Markstein's theorem) -- PROVIDED nothing under/overflows.  That is guaranteed when
-// |d| in [2^-60, 2], |o| <= 2^40 (checked once per ray; scene bounds <= 2^40 are checked at upload) and
-// |q| > 2^-40 (checked on the results, see slab_pair): then 2^-100 <= |a| <= 2^41, so every residual is representable.  Lanes failing the check (a == 0: origin exactly on a
-// bounding plane; axis-parallel rays; inf/NaN) redo the step with IEEE divisions.  The probe op 14 and
-// tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7 quotients incl. hard cases.
+// q1 is faithful, q2 = RN(a/d) (Markstein's theorem) -- PROVIDED nothing under/overflows.  That is guaranteed by a guard evaluated
+// once per ray and once per scene (ray_safe in pt_kernel.hip states it and the argument): |d| in [2^-60, 2], |o| and the plane
+// coordinates <= 2^40, and o either >= 2^-70 or 0 (0 only on axes without tiny plane coordinates), so that a = p - o is 0 or
+// >= 2^-99.  Rays failing it do the step with IEEE divisions.  The probe op 14 and tests/test_gpu_more.py::test_fast_division_is_ieee pin q2 == a/d bit for bit on 10^7
+// quotients incl. hard cases, the a == 0 zeros and the 2^-99 edge.
 __device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
     const float q0 = a * r;
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);

@@ -39,7 +39,8 @@ struct DevScene {
     const float4 *tri_pos;        //   through one buffer descriptor with a 32-bit byte offset (tri_off_bytes = n_pairs * 64)
     uint32_t tri_off_bytes, geom_bytes;
     const float4 *top;            // experiment: the first kTopPairs pairs in BFS order, child refs to cached pairs flagged (bit 30)
-    uint32_t n_top, top_pad;
+    uint32_t n_top;
+    uint32_t tiny_axes;           // bit c: some bounding plane has a coordinate 0 < |p_c| < 2^-76 on axis c (see ray_safe, pt_kernel.hip)
     const float4 *tri_attr;
     const DevMaterial *mats;
     const DevMaterialFull *mats_full;   // shading mode 1 (rt_compute.wgsl material model)

@@ -55,13 +55,24 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; 
 __device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float min3_abs(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// Per-ray guard: every |d_i| in [2^-60, 2] and every |o_i| <= 2^40.  mipt_scene_create rejects scenes whose bounds
-// exceed 2^40, so |a| = |b - o| <= 2^41 and |q| = |a/d| <= 2^101 < 2^104: no overflow anywhere in fdiv_ray, and no
-// NaN can appear (all operands finite, d != 0).  What is left to check per step is the small side (slab_pair).
-__device__ __forceinline__ bool ray_safe(V3 o, V3 d) {
+// Guard of the exact-division fast path (fdiv_ray, pt_device_math.h), evaluated ONCE PER RAY: every |d_c| in [2^-60, 2], every
+// |o_c| <= 2^40 and, per axis, |o_c| >= 2^-70 or o_c == 0 -- the latter only on axes where no bounding plane of the scene has a
+// coordinate 0 < |p_c| < 2^-76 (DevScene::tiny_axes, found by mipt_scene_create, which also refuses planes beyond 2^40).
+// Then for a = fl(p - o): |a| <= 2^41, so |q| = |a/d| <= 2^101 -- no overflow and no NaN (all operands finite, d != 0).  On the small
+// side a is exactly 0 or |a| >= 2^-99:  o = 0 gives a = p, which is 0 or >= 2^-76;  |o| >= 2^-70 with |p| < 2^-76 gives
+// |a| > 2^-71;  |o| >= 2^-70 with |p| >= 2^-76 makes both multiples of 2^-99, hence their difference too.  So q is normal and both
+// residuals a - q*d (multiples of 2^(e_a - 47) >= 2^-146) are representable: fdiv_ray returns RN(a/d).  For a == 0 every term is a
+// zero and the quotient is a zero whose sign may differ from IEEE's; a zero only ever meets min/max and ordered comparisons in
+// slab_from_t, which do not see its sign.
+__device__ __forceinline__ bool origin_safe(float x, bool zero_ok) {
+    const uint32_t m = __float_as_uint(x) & 0x7fffffffu;
+    return m >= 0x1c800000u /* 2^-70 */ || (m == 0u && zero_ok);
+}
+__device__ __forceinline__ bool ray_safe(V3 o, V3 d, uint32_t tiny_axes) {
     const float lo = 8.6736174e-19f /* 2^-60 */, hi = 2.0f, omax = 1.0995116e12f /* 2^40 */;
     return (fabsf(d.x) >= lo) && (fabsf(d.x) <= hi) && (fabsf(d.y) >= lo) && (fabsf(d.y) <= hi) &&
-           (fabsf(d.z) >= lo) && (fabsf(d.z) <= hi) && (fabsf(o.x) <= omax) && (fabsf(o.y) <= omax) && (fabsf(o.z) <= omax);
+           (fabsf(d.z) >= lo) && (fabsf(d.z) <= hi) && (fabsf(o.x) <= omax) && (fabsf(o.y) <= omax) && (fabsf(o.z) <= omax) &&
+           origin_safe(o.x, !(tiny_axes & 1u)) && origin_safe(o.y, !(tiny_axes & 2u)) && origin_safe(o.z, !(tiny_axes & 4u));
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -87,25 +98,19 @@ __device__ __forceinline__ float slab(V3 o, V3 d, float4 lo, float4 hi, float be
     return slab_from_t<CULL>((lo.x - o.x) / d.x, (lo.y - o.y) / d.y, (lo.z - o.z) / d.z,
                              (hi.x - o.x) / d.x, (hi.y - o.y) / d.y, (hi.z - o.z) / d.z, best);
 }
-// both children of a pair; fast quotients when `safe`, IEEE divisions for the lanes where the range check fails
+// both children of a pair: exact quotients by the per-ray reciprocal, computed for every lane (straight-line code in front of
+// the only branch, so the first quotients start while the later loads are still in flight; for a ray that failed ray_safe they
+// are finite-or-not garbage that traps nothing) and replaced by IEEE divisions for the lanes of such rays
 template <bool CULL>
 __device__ __forceinline__ void slab_pair(V3 o, V3 d, V3 rd, bool safe, float4 r0, float4 r1, float4 r2, float4 r3,
                                           float best, float &d1, float &d2) {
     const float a0 = r0.x - o.x, a1 = r0.y - o.y, a2 = r0.z - o.z, a3 = r1.x - o.x, a4 = r1.y - o.y, a5 = r1.z - o.z;
     const float b0 = r2.x - o.x, b1 = r2.y - o.y, b2 = r2.z - o.z, b3 = r3.x - o.x, b4 = r3.y - o.y, b5 = r3.z - o.z;
-    const float p0 = fdiv_ray(a0, d.x, rd.x), p1 = fdiv_ray(a1, d.y, rd.y), p2 = fdiv_ray(a2, d.z, rd.z);
-    const float p3 = fdiv_ray(a3, d.x, rd.x), p4 = fdiv_ray(a4, d.y, rd.y), p5 = fdiv_ray(a5, d.z, rd.z);
-    const float q0 = fdiv_ray(b0, d.x, rd.x), q1 = fdiv_ray(b1, d.y, rd.y), q2 = fdiv_ray(b2, d.z, rd.z);
-    const float q3 = fdiv_ray(b3, d.x, rd.x), q4 = fdiv_ray(b4, d.y, rd.y), q5 = fdiv_ray(b5, d.z, rd.z);
-    // small side: |q| > 2^-40 with |d| >= 2^-60 gives |a| >= 2^-100, so both residuals a - q*d are exactly
-    // representable; a == 0 (origin exactly on a bounding plane) or a denormal difference fails this and goes to
-    // the IEEE path.  (The large side and NaNs are excluded by ray_safe + the scene-bounds limit.)
-    const float mn = min3_raw(min3_abs(p0, p1, p2), min3_abs(p3, p4, p5), min_raw(min3_abs(q0, q1, q2), min3_abs(q3, q4, q5)));
-    const bool ok = safe && (mn > 9.094947e-13f /* 2^-40 */);
-    if (ok) {
-        d1 = slab_from_t<CULL>(p0, p1, p2, p3, p4, p5, best);
-        d2 = slab_from_t<CULL>(q0, q1, q2, q3, q4, q5, best);
-    } else {
+    d1 = slab_from_t<CULL>(fdiv_ray(a0, d.x, rd.x), fdiv_ray(a1, d.y, rd.y), fdiv_ray(a2, d.z, rd.z),
+                           fdiv_ray(a3, d.x, rd.x), fdiv_ray(a4, d.y, rd.y), fdiv_ray(a5, d.z, rd.z), best);
+    d2 = slab_from_t<CULL>(fdiv_ray(b0, d.x, rd.x), fdiv_ray(b1, d.y, rd.y), fdiv_ray(b2, d.z, rd.z),
+                           fdiv_ray(b3, d.x, rd.x), fdiv_ray(b4, d.y, rd.y), fdiv_ray(b5, d.z, rd.z), best);
+    if (!safe) {
         d1 = slab<CULL>(o, d, r0, r1, best);
         d2 = slab<CULL>(o, d, r2, r3, best);
     }
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
             if (start_ray) {
                 best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;
                 rd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                dir_safe = ray_safe(o, d);
+                dir_safe = ray_safe(o, d, sc.tiny_axes);
                 sp = 0; pair = LDS_TOP ? kTopFlag : 0u;
                 tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;   // root leaf (root_n > 0) or inner (empty range)
                 if (COUNT) c_rays++;
