@@ -815,16 +815,33 @@ __global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, co
     (void)block_exscan(tails, s_warp, &tt);
     if (threadIdx.x == 0) { ch[blockIdx.x].hole_cnt = th; ch[blockIdx.x].tail_cnt = tt; }
 }
-// one thread per big node: chunk bases (chunks of a node are contiguous in the chunk table, increasing offset)
-__global__ void big_scan(BigState *bs, ChunkInfo *ch, const uint32_t *chunk_begin, uint32_t nb) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per big node: chunk bases (chunks of a node are contiguous in the chunk table, increasing offset); 64 chunks per
+// step, a wave-level exclusive scan plus a running carry -- the root has 1 221 chunks, which one thread scanned in 0.28 ms
+__global__ __launch_bounds__(64) void big_scan(BigState *bs, ChunkInfo *ch, const uint32_t *chunk_begin, uint32_t nb) {
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= nb || !bs[j].split) return;
     const uint32_t cb = chunk_begin[j], ce = chunk_begin[j + 1];
     uint32_t acc = 0;
-    for (uint32_t c = cb; c < ce; c++) { ch[c].hole_base = acc; acc += ch[c].hole_cnt; }
-    bs[j].n_holes = acc;
+    for (uint32_t base = cb; base < ce; base += 64u) {                   // holes: increasing chunk index
+        const uint32_t c = base + lane;
+        const uint32_t v = c < ce ? ch[c].hole_cnt : 0u;
+        uint32_t x = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+        if (c < ce) ch[c].hole_base = acc + x - v;
+        acc += __shfl(x, 63);
+    }
+    if (lane == 0) bs[j].n_holes = acc;
     acc = 0;
-    for (uint32_t c = ce; c-- > cb;) { ch[c].tail_base = acc; acc += ch[c].tail_cnt; }
+    for (uint32_t done = 0; cb + done < ce; done += 64u) {               // tails: decreasing chunk index
+        const uint32_t q = done + lane;                                  // q-th chunk from the end
+        const bool in = q < ce - cb;
+        const uint32_t c = ce - 1u - q;
+        const uint32_t v = in ? ch[c].tail_cnt : 0u;
+        uint32_t x = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+        if (in) ch[c].tail_base = acc + x - v;
+        acc += __shfl(x, 63);
+    }
 }
 __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, uint32_t *hole_pos, uint32_t *tail_pos,
                                                const Ctrl *ctrl) {
@@ -984,11 +1001,12 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t sb = nullptr, sw = nullptr, st = nullptr;   // the three per-level kernels touch disjoint nodes: let them overlap
+    hipStream_t sb = nullptr, sw = nullptr, st = nullptr, sg = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
         if (sb) (void)hipStreamDestroy(sb);
         if (sw) (void)hipStreamDestroy(sw);
         if (st) (void)hipStreamDestroy(st);
+        if (sg) (void)hipStreamDestroy(sg);
         void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -1026,6 +1044,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipStreamCreate(&sb));                          // blocking streams: ordered against the null stream's copies / launches
     HIP_TRY(hipStreamCreate(&sw));
     HIP_TRY(hipStreamCreate(&st));
+    HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
@@ -1049,21 +1068,22 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
         const uint32_t nb = hc.cnt[parity][CLS_BIG];
-        if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk)
+        if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk);
+                                                        // its own stream: these 11 launches overlap the level's block / wave / tiny kernels
             const uint32_t nc = n_tris / kChunk + nb;   // bound on sum(ceil(n_j / kChunk)); the real count lives in ctrl->n_chunks
             if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             const dim3 gb((nb + 63) / 64), tb(64);
-            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, nullptr, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl);
-            hipLaunchKernelGGL(big_range, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_planes, dim3((nb * 3 + 63) / 64), tb, 0, nullptr, d_big, nb);
-            hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_choose, gb, tb, 0, nullptr, d_big, nb);
-            hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_scan, gb, tb, 0, nullptr, d_big, d_chunks, d_cbeg, nb);
-            hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_hp, d_tp, d_ctrl);
-            hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, nullptr, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
-            hipLaunchKernelGGL(big_finish, gb, tb, 0, nullptr, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
+            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl);
+            hipLaunchKernelGGL(big_range, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_planes, dim3((nb * 3 + 63) / 64), tb, 0, sg, d_big, nb);
+            hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_choose, gb, tb, 0, sg, d_big, nb);
+            hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_scan, dim3(nb), dim3(64), 0, sg, d_big, d_chunks, d_cbeg, nb);
+            hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_hp, d_tp, d_ctrl);
+            hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
+            hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
         }
         const uint32_t nblk = hc.cnt[parity][CLS_BLOCK], nwav = hc.cnt[parity][CLS_WAVE], ntin = hc.cnt[parity][CLS_TINY];
         if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kT), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);

@@ -59,5 +59,8 @@ for path in args.libs:
         st = L.MiptStats()
         assert lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st)) == 0
         extra = f"  rays {st.rays} inner {st.inner_steps} tri {st.tri_tests}  -> {st.rays / min(ts) / 1e3:.0f} Mray/s, {(st.inner_steps + st.tri_tests) / min(ts) / 1e6:.2f} G lane-steps/s"
+        dg = list(st.diag)
+        extra += (f"\n    wave iterations {dg[0]} (inner branch in {dg[3]}, leaf branch in {dg[4]}), lanes per iteration inner {dg[1] / max(dg[3], 1):.1f} leaf {dg[2] / max(dg[4], 1):.1f};"
+                  f" service passes {dg[5]} with {dg[6] / max(dg[5], 1):.1f} lanes; wave-cycles (100 MHz stamps) in service {dg[7] / max(dg[8], 1):.3f}, tail {dg[10] / max(dg[8], 1):.3f} of {dg[8]}")
     lib.mipt_scene_destroy(hnd)
     print(f"{os.path.basename(path):40s} min {min(ts):8.3f} ms  median {sorted(ts)[len(ts) // 2]:8.3f} ms  crc {zlib.crc32(buf.tobytes()):08x}{extra}", flush=True)
