@@ -358,6 +358,14 @@ __device__ __forceinline__ float rand_f32_nd(uint32_t &s, TabPtr logtab) {
     float rho = __builtin_sqrtf(-2.0f * gl_log10f_unit(rand_f32(s), logtab));
     return rho * gl_cosf_2pi(theta);
 }
+// The arithmetic of one rand_f32_nd draw given its two uniforms (u_theta drawn first, u_rho second): the same operations in
+// the same order, so the same bits -- the kernel's service pass evaluates the three draws of a scatter on three lanes at once.
+template <class TabPtr>
+__device__ __forceinline__ float rand_f32_nd_eval(float u_theta, float u_rho, TabPtr logtab) {
+    const float theta = 6.283185f * u_theta;
+    const float rho = __builtin_sqrtf(-2.0f * gl_log10f_unit(u_rho, logtab));
+    return rho * gl_cosf_2pi(theta);
+}
 // vec3.rs:66-68 -- x, y, z drawn in that order
 template <class TabPtr>
 __device__ __forceinline__ V3 rand_in_unit_sphere(uint32_t &s, TabPtr logtab) {

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];   // row kStackLds: scratch target of the branch-free push
     __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
     __shared__ double s_logtab[32];                                    // __logf_data.tab (16 x {invc, logc}) for gl_log10f
+    __shared__ __attribute__((aligned(16))) float s_draw[kWavesPerBlock][64 * 6];                   // scatter draws of a service pass: 3 x {u_theta, u_rho} per hit lane, compacted
     if (threadIdx.x < 32u) s_logtab[threadIdx.x] = gl_d(glibc_logf_tab, (int)threadIdx.x);
     __syncthreads();
     if (LDS_TOP) {
@@ -366,8 +367,10 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
         if (n_need != 0u && (n_t == 0u || n_need * pr.service_den >= (n_t + n_need) * pr.service_num)) {
             if (COUNT) { g_serv++; g_serv_lanes += n_need; g_t0 = clock64(); }
             bool start_ray = false;
+            bool scatter = false;                                                  // CPU-backend shading: this lane hit and draws a new direction
+            V3 sc_normal = mk(0, 0, 0);
+            bool path_done = false;
             if (state == ST_S) {
-                bool path_done;
                 if (SHADING == 1 && best_tri != kNoTri) {                          // rt_compute.wgsl:137-213
                     bounces += 1;                                                  // curr_ray_depth += 1 (before the cut-out test)
                     uint32_t n_tex = 0;
@@ -388,7 +391,6 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
                     if (!(best_tri & kFrontBit)) normal = mk(-normal.x, -normal.y, -normal.z); // ray.rs:46-48
                     const float uvx = ((a2.y * w) + (a2.w * u)) + (a3.y * v);       // ray.rs:50-53
                     const float uvy = ((a2.z * w) + (a3.x * u)) + (a3.z * v);
-                    const V3 point = o + d * best_t;                                // ray.rs:60
                     const DevMaterial m = sc.mats[__float_as_uint(a3.w)];           // ray.rs:153-154
                     if (m.base_w != 0u) {                                           // ray.rs:162-169
                         ray_color = ray_color * texel_rgb(sc, m.base_off, m.base_w, m.base_h, uvx, uvy, pr.stats);
@@ -403,18 +405,52 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
                         emitted = emitted + mk(m.emis[0], m.emis[1], m.emis[2]);
                     }
                     incoming = incoming + emitted * ray_color;                       // ray.rs:177
-                    const V3 new_dir = normalized(normal + rand_in_unit_sphere(rng, (const double *)s_logtab)); // ray.rs:179-180
-                    o = point + new_dir * 0.0001f;                                   // ray.rs:181
-                    d = new_dir;
-                    bounces += 1;
+                    scatter = true; sc_normal = normal;                              // ray.rs:179-183 follow below, wave-cooperatively
                     if (COUNT) c_hits++;
-                    path_done = !(bounces < pr.max_depth);                           // ray.rs:147
                 } else {                                                             // ray.rs:184-193
                     ray_color = ray_color * mk(1.0f, 1.0f, 1.0f);
                     emitted = emitted + mk(1.0f, 1.0f, 1.0f);
                     incoming = incoming + emitted * ray_color;
                     path_done = true;
                 }
+            }
+            if (SHADING == 0) {
+                // ---- Vec3f::rand_in_unit_sphere (vec3.rs:66-68) for every hit lane of the pass, spread over the whole wave ----
+                // A scatter draws three rand_f32_nd (math.rs:15-19): six xorshift steps on the lane's own stream, then three
+                // evaluations of sqrt(-2 log10 u_rho) * cos(6.283185 u_theta) that depend on nothing but their two uniforms.  Only
+                // ~a quarter of the lanes are in the pass and the rest would sit out ~1 000 instructions of f64 arithmetic: so
+                // the 3 h evaluations of the pass's h hit lanes are compacted through LDS (item 3 * rank + k at float2 slot
+                // 3 * rank + k) and every lane of the wave -- whatever its own state -- evaluates item `lane` (+64, +128 when
+                // 3 h > 64) and writes the result over the item's first word.  Same operations on the same operands: same bits.
+                float *dr = s_draw[wib];
+                const unsigned long long m_sc = __ballot(scatter);
+                const uint32_t n_items = 3u * (uint32_t)__popcll(m_sc);
+                if (n_items != 0u) {                                                 // wave-uniform
+                    const uint32_t base = 6u * lane_rank(m_sc);
+                    if (scatter) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) dr[base + k] = rand_f32(rng);  // u_theta, u_rho of x; of y; of z -- the draw order of vec3.rs:67
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t item = lane; item < n_items; item += 64u) {
+                        const float2 uu = *reinterpret_cast<const float2 *>(dr + 2u * item);
+                        dr[2u * item] = rand_f32_nd_eval(uu.x, uu.y, (const double *)s_logtab);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (scatter) {
+                        const V3 rs = normalized(mk(dr[base], dr[base + 2u], dr[base + 4u]));
+                        const V3 point = o + d * best_t;                             // ray.rs:60
+                        const V3 new_dir = normalized(sc_normal + rs);              // ray.rs:179-180
+                        o = point + new_dir * 0.0001f;                               // ray.rs:181
+                        d = new_dir;
+                        bounces += 1;
+                        path_done = !(bounces < pr.max_depth);                       // ray.rs:147
+                    }
+                }
+            }
+            if (state == ST_S) {
                 if (path_done) {
                     const V3 res = (bounces == 0u) ? incoming : incoming / (float)bounces; // ray.rs:197-201
                     final_color = final_color + res;                                 // cpu.rs:52
