@@ -427,7 +427,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     pr.aspect = (float)opt->width / (float)opt->height;       // cpu.rs:34
     pr.samples_f = (float)opt->samples;                       // cpu.rs:60
     pr.cull_scale = 1.0f + opt->cull_margin;
-    pr.service_num = 1; pr.service_den = 4; pr.reverse_tiles = 0;
+    pr.service_num = 3; pr.service_den = 8; pr.reverse_tiles = 0;   // service pass when >= 3/8 of the live lanes wait for one (tools/sweep_service.py)
     pr.lds_top = 0;
 #ifdef MIPT_TUNING   // experiment knobs exist only in a `make TUNING=1` build (tools/README.md); the product reads no environment
     if (const char *e = getenv("MIPT_LDS_TOP")) pr.lds_top = atoi(e) ? 1u : 0u;

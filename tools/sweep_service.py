@@ -10,15 +10,16 @@ buf = np.zeros(w * h * 3, dtype=np.float32)
 cases = [("config2 helmet", "helmet", dict(n_target=15000, tex_size=1024), 16), ("config3 dragon", "dragon", dict(n_target=870000), 64),
          ("configM atrium", "atrium", dict(n_target=int(os.environ.get("SWEEP_TRIS", "10000000")), tex_size=1024), 8)]
 for name, kind, kw, spp in cases:
+    if os.environ.get("SWEEP_ONLY") and os.environ["SWEEP_ONLY"] not in name: continue
     tris, mats, texs, cam = synth.make_scene(kind, **kw)
     sc = rrt.Scene.from_arrays(tris, mats, texs)
     sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
     hnd = sc.upload(0)
     res = {}
-    for num, den in [(1, 8), (1, 4), (3, 8), (1, 2), (5, 8), (3, 4), (7, 8), (1, 1)]:
+    for num, den in [(1, 8), (3, 16), (1, 4), (5, 16), (3, 8), (1, 2), (5, 8), (3, 4)]:
         os.environ["MIPT_SERVICE_NUM"], os.environ["MIPT_SERVICE_DEN"] = str(num), str(den)
         ts = []
-        for rep in range(3):
+        for rep in range(int(os.environ.get("SWEEP_REPS", "3"))):
             o = rrt.make_options(w, h, spp, 64, traversal=1)
             st = L.MiptStats()
             L.check(lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st)), "render")
