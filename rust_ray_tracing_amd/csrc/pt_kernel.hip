@@ -7,6 +7,8 @@
 // refilled from a global queue with one wave-aggregated atomic (ballot + mbcnt compaction);
 // shading / ray generation is deferred until a ballot says enough lanes need it, so the
 // divergent "service" code runs with many lanes active instead of once per finished ray.
+// Inside a service pass the three normal draws of every scatter -- the pass's heaviest arithmetic --
+// are spread over ALL lanes of the wave through LDS, whatever those lanes' own state.
 //
 // Traversal restates Ray::traverse_bvh (reference src/renderer/backend/cpu/ray.rs:84-139)
 // step for step -- same visit order, same strict-< closest hit -- over re-based 64-byte child
