@@ -41,6 +41,7 @@ __global__ void debug_eval_kernel(int op, const float *__restrict__ a, const flo
         case 18: r = gl_logf(x, GlTabGlobal()); break;
         case 19: r = gl_log10f_unit(x, GlTabGlobal()); break;                              // valid on {0} u [2^-32, 1]
         case 20: r = gl_cosf_2pi(x); break;                                                // valid on [0, 6.2831855]
+        case 23: r = __uint_as_float(floor_mod((int32_t)__float_as_uint(x), __float_as_uint(y))); break;   // |i| < 2^30, W >= 1
         default: break;
         }
         out[i] = r;

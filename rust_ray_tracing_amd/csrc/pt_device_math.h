@@ -403,6 +403,14 @@ __device__ __forceinline__ float fdiv_ray(float a, float d, float r) {
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d, a), r, q0);
     return __builtin_fmaf(__builtin_fmaf(-q1, d, a), r, q1);
 }
+// floored i mod W for |i| < 2^30, W in [1, 2^32): one 32-bit unsigned division instead of the two 64-bit ones of
+// ((i % W) + W) % W -- hipcc expands a 64-bit modulo to ~100 instructions (the bilinear sampler of shading mode 1 wraps four
+// coordinates per sample)
+__device__ __forceinline__ uint32_t floor_mod(int32_t i, uint32_t W) {
+    const uint32_t a = (uint32_t)(i ^ (i >> 31));        // i >= 0: i;  i < 0: -i - 1
+    const uint32_t m = a % W;
+    return i >= 0 ? m : W - 1u - m;
+}
 // u8 -> f32 / 255.0 (vec3.rs:252-260) with the same exact two-correction quotient as fdiv_ray: the numerator is an
 // integer in [0, 255] and the divisor the constant 255, so no range guard is needed (0 gives 0 exactly);
 // tests/test_gpu_more.py checks all 256 values against IEEE division.

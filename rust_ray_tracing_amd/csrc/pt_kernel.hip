@@ -143,14 +143,6 @@ __device__ __forceinline__ V3 texel_rgb(const DevScene &sc, uint32_t offset, uin
 struct V4 { float x, y, z, w; };
 __device__ __forceinline__ float w_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// floored i mod W for |i| < 2^30 (the texel coordinate below is clamped to that), W in [1, 2^32): one 32-bit unsigned division
-// instead of the two 64-bit ones of ((i % W) + W) % W -- hipcc expands a 64-bit modulo to ~100 instructions, and the bilinear
-// footprint needs eight of them per sample
-__device__ __forceinline__ uint32_t floor_mod(int32_t i, uint32_t W) {
-    const uint32_t a = (uint32_t)(i ^ (i >> 31));                           // i >= 0: i;  i < 0: -i - 1
-    const uint32_t m = a % W;
-    return i >= 0 ? m : W - 1u - m;
-}
 __device__ __forceinline__ V4 sample_texture_bilinear(const uint32_t *texels, uint32_t offset, uint32_t width, uint32_t height, float u, float v) {
     const uint32_t W = width, H = height;                                    // textureSampleLevel: linear, repeat (gpu.rs:393-401)
     const float uu = u * (float)W - 0.5f, vv = v * (float)H - 0.5f;
@@ -159,7 +151,7 @@ __device__ __forceinline__ V4 sample_texture_bilinear(const uint32_t *texels, ui
     const int32_t ic = (fabsf(fu) < 1e9f) ? (int32_t)fu : 0, jc = (fabsf(fv) < 1e9f) ? (int32_t)fv : 0;
     if (!(a == a)) a = 0.0f;
     if (!(b == b)) b = 0.0f;
-    const uint32_t i0 = floor_mod(ic, W), j0 = floor_mod(jc, H);             // texel (ic, jc) and its +1 neighbours, wrapped
+    const uint32_t i0 = floor_mod(ic, W), j0 = floor_mod(jc, H);             // texel (ic, jc) and its +1 neighbours, wrapped (|ic|, |jc| < 1e9)
     const uint32_t i1 = (i0 + 1u == W) ? 0u : i0 + 1u, j1 = (j0 + 1u == H) ? 0u : j0 + 1u;
     const size_t row0 = (size_t)offset + (size_t)j0 * W, row1 = (size_t)offset + (size_t)j1 * W;
     const uint32_t p00 = texels[row0 + i0], p10 = texels[row0 + i1];

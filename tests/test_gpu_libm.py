@@ -69,3 +69,20 @@ def test_the_kernels_specialised_log10f_and_cosf_equal_the_general_functions_on_
     assert _sweep(rrt, orc, 20, 0, top, ref_op=0) == (0, [])
     assert _sweep(rrt, orc, 19, 0, 0, ref_op=1) == (0, [])                             # log10(0) = -inf
     assert _sweep(rrt, orc, 19, _bits(2.0 ** -32), _bits(1.0), ref_op=1) == (0, [])
+
+
+def test_floor_mod_of_the_bilinear_sampler(rrt):
+    """Shading mode 1's texture wrap (rt_compute.wgsl textureSampleLevel, repeat addressing): floor_mod(i, W) == i mod W in the
+    floored sense for |i| < 2^30 and every W in [1, 2^32), on edge cases and two million random pairs."""
+    diag = rrt.load_diag()
+    rng = np.random.default_rng(5)
+    edge_i = np.array([0, 1, -1, 2, -2, 2 ** 30 - 1, -(2 ** 30 - 1), 999_999_999, -999_999_999, 12345, -12345], dtype=np.int64)
+    edge_w = np.array([1, 2, 3, 7, 255, 256, 1000, 65535, 65536, 2 ** 30 - 1, 2 ** 30, 2 ** 30 + 1, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1], dtype=np.int64)
+    ii, ww = np.meshgrid(edge_i, edge_w)
+    i = np.concatenate([ii.ravel(), rng.integers(-(2 ** 30) + 1, 2 ** 30, 2_000_000)])
+    w = np.concatenate([ww.ravel(), np.where(rng.random(2_000_000) < 0.5, rng.integers(1, 5000, 2_000_000), rng.integers(1, 2 ** 32, 2_000_000))])
+    a = i.astype(np.int32).view(np.float32).copy()
+    bb = w.astype(np.uint32).view(np.float32).copy()
+    out = np.zeros(a.size, dtype=np.float32)
+    assert diag.mipt_debug_eval(23, a.ctypes.data, bb.ctypes.data, a.size, out.ctypes.data) == 0
+    assert np.array_equal(out.view(np.uint32).astype(np.int64), np.mod(i, w))
