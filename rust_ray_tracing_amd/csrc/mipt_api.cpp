@@ -453,8 +453,15 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
         const int cap = (int)(fit < 2 ? 2 : fit);
         if (cap < bpc) bpc = cap;
     }
+    // Leaf phases (pt_kernel.hip): worth it when the SIMDs are the limit, i.e. every lane has many pixels to work through (full
+    // 1080p frame, 6.3 pixels per resident lane: 83.0 -> 78.8 ms at period 4); a tile shard with 3.2 / 1.6 / 0.8 pixels per lane
+    // (world 2 / 4 / 8) spends most of its time in the latency-bound tail and is 2 - 8 % slower with it: period 1 there
+    pr.leaf_period = (pr.total_work >= 4ull * (unsigned long long)scene->n_cu * (unsigned long long)occ * mipt::kBlockThreads) ? 4u : 1u;
+    pr.leaf_den = 4u;
 #ifdef MIPT_TUNING
     if (const char *env = getenv("MIPT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) bpc = v < occ ? v : occ; }
+    if (const char *env = getenv("MIPT_LEAF_PERIOD")) { int v = atoi(env); if (v >= 1 && v <= 64) pr.leaf_period = (uint32_t)v; }
+    if (const char *env = getenv("MIPT_LEAF_DEN")) { int v = atoi(env); if (v >= 0 && v <= 64) pr.leaf_den = (uint32_t)v; }
 #endif
     long long grid = (long long)scene->n_cu * bpc;
     const long long need_blocks = (long long)((pr.total_work + mipt::kBlockThreads - 1) / mipt::kBlockThreads);

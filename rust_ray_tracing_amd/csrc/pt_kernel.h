@@ -72,6 +72,8 @@ struct DevParams {
     uint32_t reverse_tiles;                 // hand out the tile list back to front (bottom rows first)
     uint32_t lds_top;                       // experiment: serve the first kTopPairs pairs from LDS
     uint32_t service_num, service_den;      // run the service pass when need/live >= num/den
+    uint32_t leaf_period, leaf_den;         // triangle tests run when leaf_period iterations have passed since the last ones or
+                                            // 1/leaf_den of the traversing lanes wait for one (pt_kernel.hip "leaf phases"); period 1 = always
     float cam[12];                          // look_at columns 0..2 (xyz each), position
     float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
     uint32_t *ovf;                          // traversal-stack overflow area [wave][entry][lane]

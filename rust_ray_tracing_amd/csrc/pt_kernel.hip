@@ -360,6 +360,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
     unsigned long long g_iters = 0, g_inner = 0, g_leaf = 0, g_it_inner = 0, g_it_leaf = 0, g_serv = 0, g_serv_lanes = 0;  // lane 0 only
     unsigned long long g_t_serv = 0, g_t_start = COUNT ? clock64() : 0ull, g_t0 = 0, g_t_mem = 0, g_t_first_x = 0;
 
+    uint32_t leaf_wait = 0;                                // wave-uniform: iterations until the next scheduled leaf phase
     for (;;) {
         const unsigned long long m_t = __ballot(state == ST_T);
         const unsigned long long m_need = __ballot(state != ST_T && state != ST_X);
@@ -549,14 +550,24 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
         }
 
         // ---------------- one traversal step per traversing lane ---------------------------------
-        // (Leaf batching -- parking lanes at leaves until >= N of the wave are there -- was measured and is slower at
-        //  every N: 100.3 ms at N=1 (off) vs 105/112/133 ms at N=8/16/32; every lane's step chain is on the critical path.)
-        if (COUNT) {
-            const unsigned long long m_leaf = __ballot(state == ST_T && tri_cur < tri_end);
-            const uint32_t nl = (uint32_t)__popcll(m_leaf);
-            g_iters++; g_leaf += nl; g_inner += n_t - nl; g_it_leaf += (nl != 0u); g_it_inner += (n_t != nl);
+        // Leaf phases.  On the 10 M-triangle scene ~5 of the wave's 64 lanes are at a triangle in any one iteration, yet the
+        // Moeller-Trumbore block costs the wave as much as it would for 64.  So triangle tests run only in a "leaf phase": when
+        // pr.leaf_period iterations have passed since the last one, when at least 1/pr.leaf_den of the traversing lanes wait for
+        // one, or when no lane has an inner step to do; lanes that reach a leaf in between sit out.  Pure scheduling: a lane's
+        // own sequence of steps is unchanged.  Period 4 on the full frame of config M: 82.4 -> 79.4 ms (2: 81.2, 3: 80.2, 5: 79.5,
+        // 6: 81.1, 8: 84.1).  The fraction release is what lets scenes with many leaf visits gain too (dragon, 5.5 triangle tests
+        // per 18.5 inner steps: a bare period 4 costs it 16 %, with release at 1/4 it gains 4 %; helmet +9 % / -2 %;
+        // tools/sweep_service.py).  A tile shard (1/2 ... 1/8 frame) is bound by its longest pixel chain, where waiting costs
+        // 2 - 8 %: the host passes period 1 (mipt_api.cpp).
+        bool leaf_hold;
+        {
+            const unsigned long long m_lf = __ballot(state == ST_T && tri_cur < tri_end);
+            const unsigned long long m_in = __ballot(state == ST_T && !(tri_cur < tri_end));
+            const bool phase = leaf_wait == 0u || m_in == 0ull || (uint32_t)__popcll(m_lf) * pr.leaf_den >= n_t;
+            leaf_wait = phase ? pr.leaf_period - 1u : leaf_wait - 1u;
+            leaf_hold = !phase;
         }
-        if (state == ST_T) {
+        if (state == ST_T && !(leaf_hold && tri_cur < tri_end)) {
             const bool leaf = tri_cur < tri_end;
             // one buffer descriptor over [pairs | tri_pos], 32-bit byte offset per lane (no 64-bit address math)
             const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * 48u) : (pair * 64u);

@@ -39,7 +39,7 @@ def test_diag_probe_is_a_separate_library(rrt):
     assert "debug_eval" not in out and "mipt_diag" not in out
     # and the product reads no tuning knob from the environment (those exist only in a `make TUNING=1` build)
     strings = subprocess.run(["strings", L.LIB_PATH], capture_output=True, text=True).stdout
-    for knob in ("MIPT_LDS_TOP", "MIPT_REVERSE_TILES", "MIPT_SERVICE_NUM", "MIPT_SERVICE_DEN", "MIPT_BLOCKS_PER_CU"):
+    for knob in ("MIPT_LDS_TOP", "MIPT_REVERSE_TILES", "MIPT_SERVICE_NUM", "MIPT_SERVICE_DEN", "MIPT_BLOCKS_PER_CU", "MIPT_LEAF_PERIOD", "MIPT_LEAF_DEN"):
         assert knob not in strings, knob
 
 

@@ -34,7 +34,12 @@ w, h = 1920, 1080
 n_out = int(rrt.load().mipt_packed_pixels(w, h, args.world)) if args.world > 1 else w * h
 buf = np.zeros(n_out * 3, dtype=np.float32)
 desc = sc.desc()
-for path in args.libs:
+for spec in args.libs:
+    # "lib.so@VAR=VAL,VAR2=VAL2": environment set while this library renders (knobs of a `make TUNING=1` / -DMIPT_TUNING build)
+    path, _, envs = spec.partition("@")
+    set_env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    for k in [k for k in os.environ if k.startswith("MIPT_")]: del os.environ[k]
+    os.environ.update(set_env)
     lib = C.CDLL(os.path.abspath(path), mode=C.RTLD_LOCAL)
     vp = C.c_void_p
     lib.mipt_scene_create.argtypes = [C.POINTER(L.MiptSceneDesc), C.c_int, C.POINTER(vp)]
@@ -63,4 +68,4 @@ for path in args.libs:
         extra += (f"\n    wave iterations {dg[0]} (inner branch in {dg[3]}, leaf branch in {dg[4]}), lanes per iteration inner {dg[1] / max(dg[3], 1):.1f} leaf {dg[2] / max(dg[4], 1):.1f};"
                   f" service passes {dg[5]} with {dg[6] / max(dg[5], 1):.1f} lanes; wave-cycles (100 MHz stamps) in service {dg[7] / max(dg[8], 1):.3f}, tail {dg[10] / max(dg[8], 1):.3f} of {dg[8]}")
     lib.mipt_scene_destroy(hnd)
-    print(f"{os.path.basename(path):40s} min {min(ts):8.3f} ms  median {sorted(ts)[len(ts) // 2]:8.3f} ms  crc {zlib.crc32(buf.tobytes()):08x}{extra}", flush=True)
+    print(f"{os.path.basename(spec):40s} min {min(ts):8.3f} ms  median {sorted(ts)[len(ts) // 2]:8.3f} ms  crc {zlib.crc32(buf.tobytes()):08x}{extra}", flush=True)

@@ -26,4 +26,18 @@ for name, kind, kw, spp in cases:
             ts.append(st.kernel_ms)
         res[f"{num}/{den}"] = round(min(ts), 2)
     print(name, res, flush=True)
+    if os.environ.get("SWEEP_LEAF"):                       # leaf-phase period (MIPT_LEAF_PERIOD) at the default service threshold
+        del os.environ["MIPT_SERVICE_NUM"], os.environ["MIPT_SERVICE_DEN"]
+        res = {}
+        for per, lanes in [tuple(int(v) for v in x.split("/")) for x in os.environ["SWEEP_LEAF"].split(",")]:   # "4/16,4/65,..."
+            os.environ["MIPT_LEAF_PERIOD"], os.environ["MIPT_LEAF_DEN"] = str(per), str(lanes)
+            ts = []
+            for rep in range(int(os.environ.get("SWEEP_REPS", "3"))):
+                o = rrt.make_options(w, h, spp, 64, traversal=1)
+                st = L.MiptStats()
+                L.check(lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st)), "render")
+                ts.append(st.kernel_ms)
+            res[f"period {per} release 1/{lanes}"] = round(min(ts), 2)
+        del os.environ["MIPT_LEAF_PERIOD"], os.environ["MIPT_LEAF_DEN"]
+        print(name, res, flush=True)
     del sc
