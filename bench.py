@@ -52,7 +52,7 @@ def algorithmic_bytes(st: dict, n_samples: int) -> int:
 
 def device_bytes(st: dict, n_pixels: int) -> int:
     """Bytes the kernel's loads actually request in the DEVICE layout: one 64-B record per inner step,
-    64 B per triangle test (48-B record + the shared fourth 16-B load), per hit 64 B attributes + 64 B material, 4 B per
+    64 B per triangle test (one 64-B-strided record), per hit 64 B attributes + 64 B material, 4 B per
     texel, 12 B per pixel written."""
     return (64 * st["inner_steps"] + 64 * st["tri_tests"] + 128 * st["hits"] + 4 * st["texel_fetches"] + 12 * n_pixels)
 

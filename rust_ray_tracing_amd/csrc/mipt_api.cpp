@@ -176,7 +176,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         }
     }
     // ---- triangles: 48-B intersection stream + 64-B shading stream ----
-    std::vector<float4> tri_pos((size_t)desc->n_tris * 3 + 1);   // +1: the kernel's unconditional 4th float4 load
+    std::vector<float4> tri_pos((size_t)desc->n_tris * mipt::kTriPosStride / 16 + 1);   // +1: the kernel's unconditional 4th float4 load
     std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
     for (uint32_t i = 0; i < desc->n_tris; i++) {
         const MiptTriangle &t = desc->tris[i];
@@ -187,9 +187,10 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         // the same value the reference recomputes per test (-ffp-contract=off; no fusing possible here).
         const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
         const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
-        tri_pos[(size_t)i * 3 + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
-        tri_pos[(size_t)i * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
-        tri_pos[(size_t)i * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+        const size_t q = (size_t)i * (mipt::kTriPosStride / 16);
+        tri_pos[q + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
+        tri_pos[q + 1] = make_float4(e1y, e1z, e2x, e2y);
+        tri_pos[q + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
         const MiptVec3 n0 = t.vertices[0].normal, n1 = t.vertices[1].normal, n2 = t.vertices[2].normal;
         float mid;
         memcpy(&mid, &t.material_id, 4);
@@ -198,7 +199,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         tri_attr[(size_t)i * 4 + 2] = make_float4(n2.z, t.vertices[0].tex_coord_x, t.vertices[0].tex_coord_y, t.vertices[1].tex_coord_x);
         tri_attr[(size_t)i * 4 + 3] = make_float4(t.vertices[1].tex_coord_y, t.vertices[2].tex_coord_x, t.vertices[2].tex_coord_y, mid);
     }
-    tri_pos[(size_t)desc->n_tris * 3] = make_float4(0, 0, 0, 0);
+    tri_pos[(size_t)desc->n_tris * (mipt::kTriPosStride / 16)] = make_float4(0, 0, 0, 0);
     // ---- materials / textures ----
     struct TexDesc { uint32_t offset, width, height; };
     std::vector<TexDesc> texs(desc->n_textures);

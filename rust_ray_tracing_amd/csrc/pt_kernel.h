@@ -10,7 +10,8 @@ namespace mipt {
 //            (children are always pushed adjacently at odd indices, bvh.rs:121,131-132), each
 //            child kept in the reference's Node layout {min.xyz, a, max.xyz, n}: n = num_tris;
 //            a = first triangle (leaf) or the PAIR index of its own children (inner).
-// tri_pos  : n_tris x 48 B intersection stream {v0.xyz, e1.xyz, e2.xyz, 3 pad words},
+// tri_pos  : n_tris x 64 B intersection stream {v0.xyz, e1.xyz, e2.xyz, 7 pad words} (a 48-B stride straddles 128-B lines:
+//            1.41 memory requests per record instead of 1),
 //            e1 = v1 - v0, e2 = v2 - v0 rounded once on the host exactly as ray.rs:24-25 does.
 // tri_attr : n_tris x 64 B shading stream {n0,n1,n2 (9 f32), uv0,uv1,uv2 (6 f32), material_id}.
 // mats     : n_materials x 64 B {base_color.xyz, emission.xyz} -- the only Material fields cpu/ray.rs:162-176 reads --
@@ -83,6 +84,10 @@ struct DevParams {
 constexpr int kStackLds = 16;               // per-lane traversal-stack entries held in LDS
 constexpr int kStackOvf = 48;               // further entries spilled to HBM (rarely touched)
 constexpr int kWavesPerBlock = 4;
+#ifndef MIPT_TRI_POS_STRIDE
+#define MIPT_TRI_POS_STRIDE 64
+#endif
+constexpr uint32_t kTriPosStride = MIPT_TRI_POS_STRIDE;   // bytes per record of the intersection stream: 48 packed, 64 = never straddles a 128-B line
 constexpr int kTopPairs = 127;              // tree-top pairs staged in LDS (7 levels, 8 KB per block) when MIPT_LDS_TOP is on
 constexpr uint32_t kTopFlag = 0x40000000u;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;

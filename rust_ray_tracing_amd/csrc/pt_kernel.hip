@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
         if (state == ST_T && !(leaf_hold && tri_cur < tri_end)) {
             const bool leaf = tri_cur < tri_end;
             // one buffer descriptor over [pairs | tri_pos], 32-bit byte offset per lane (no 64-bit address math)
-            const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * 48u) : (pair * 64u);
+            const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * kTriPosStride) : (pair * 64u);
             unsigned long long g_ta = 0;
             if (COUNT && DIAG_STAMPS) g_ta = clock64();
             // top of the stack, read now so that its LDS latency hides under the global loads: a step that pops never pushes
