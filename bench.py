@@ -60,7 +60,7 @@ def device_bytes(st: dict, n_pixels: int) -> int:
 def kernel_source_sha() -> str:
     """Identifies the trace kernel's source: a committed PMC summary is only quoted if it was measured on this source."""
     h = hashlib.sha256()
-    for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h"):
+    for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp"):
         with open(os.path.join(ROOT, "rust_ray_tracing_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
