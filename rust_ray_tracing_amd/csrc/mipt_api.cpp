@@ -194,26 +194,21 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             *out = (n.first_tri_or_child - 1u) / 2u;
             return true;
         };
-        std::vector<uint32_t> couples, singles;
-        // breadth-first from `level` for at most `max_levels` levels; returns the level that was not placed any more
-        auto bfs = [&](std::vector<uint32_t> level, uint32_t max_levels) {
-            for (uint32_t l = 0; l < max_levels && !level.empty(); l++) {
-                if (order.size() & 1u) order.push_back(0xffffffffu);        // every level starts on a line boundary
-                for (uint32_t k : level) order.push_back(k);
-                couples.clear(); singles.clear();
-                for (uint32_t k : level) {
-                    uint32_t ca = 0, cb = 0;
-                    const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
-                    if (ha && hb) { couples.push_back(ca); couples.push_back(cb); } // an even count in front keeps couples line-aligned
-                    else if (ha) singles.push_back(ca);
-                    else if (hb) singles.push_back(cb);
-                }
-                level = couples;
-                level.insert(level.end(), singles.begin(), singles.end());
+        std::vector<uint32_t> level{0u}, couples, singles;
+        while (!level.empty()) {
+            if (order.size() & 1u) order.push_back(0xffffffffu);            // every level starts on a line boundary
+            for (uint32_t k : level) order.push_back(k);
+            couples.clear(); singles.clear();
+            for (uint32_t k : level) {
+                uint32_t ca = 0, cb = 0;
+                const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
+                if (ha && hb) { couples.push_back(ca); couples.push_back(cb); }     // an even count in front keeps couples line-aligned
+                else if (ha) singles.push_back(ca);
+                else if (hb) singles.push_back(cb);
             }
-            return level;
-        };
-        (void)bfs(std::vector<uint32_t>{0u}, 0xffffffffu);
+            level = couples;
+            level.insert(level.end(), singles.begin(), singles.end());
+        }
         if (order.size() > (size_t)mipt::kMaxPairs) return fail(MIPT_ERR_SCENE_LIMIT, "%zu pair records exceed the 2^24 device-format limit", order.size());
         for (size_t j = 0; j < order.size(); j++) if (order[j] != 0xffffffffu) new_of[order[j]] = (uint32_t)j;
         std::vector<float4> re(order.size() * 4, make_float4(0, 0, 0, 0));
@@ -229,7 +224,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     }
 #endif
     const uint32_t n_pair_records = (uint32_t)(pairs.size() / 4);
-    // ---- triangles: 48-B intersection stream + 64-B shading stream ----
+    // ---- triangles: 64-B-strided intersection stream + 64-B shading stream ----
     std::vector<float4> tri_pos((size_t)desc->n_tris * mipt::kTriPosStride / 16 + 1);   // +1: the kernel's unconditional 4th float4 load
     std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
     for (uint32_t i = 0; i < desc->n_tris; i++) {
