@@ -265,3 +265,45 @@ extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nod
         return MIPT_ERR_INVALID_ARG;
     }
 }
+
+// ---- order of the device's 64-B pair records (pair k = {nodes[2k+1], nodes[2k+2]}; mipt_api.cpp builds the records) ----
+// Breadth-first, every level starting on a 128-B line (an even record index), and within a level first the couples -- the two
+// child pairs of a node with two inner children, adjacent: one line -- then the child pairs of nodes with one inner child.
+// order_out[j] = reference pair index of record j, or 0xffffffff for a pad record; *n_records_out = number of records.
+// Internal to the library (declared where it is used); exported for tests/test_host_layout.py.
+extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out) {
+    if (!nodes || !order_out || !n_records_out || (n_nodes & 1u) == 0u) return MIPT_ERR_INVALID_ARG;
+    try {
+        const uint32_t n_pairs = (n_nodes - 1u) / 2u;
+        std::vector<uint32_t> order;
+        order.reserve((size_t)n_pairs + 64);
+        auto child_pair = [&](uint32_t k, uint32_t w, uint32_t *out) -> bool {
+            const MiptNode &n = nodes[2 * k + 1 + w];
+            if (n.num_tris != 0u) return false;
+            *out = (n.first_tri_or_child - 1u) / 2u;
+            return true;
+        };
+        std::vector<uint32_t> level, couples, singles;
+        if (n_pairs > 0) level.push_back(0u);
+        while (!level.empty()) {
+            if (order.size() & 1u) order.push_back(0xffffffffu);            // every level starts on a line boundary
+            for (uint32_t k : level) order.push_back(k);
+            couples.clear(); singles.clear();
+            for (uint32_t k : level) {
+                uint32_t ca = 0, cb = 0;
+                const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
+                if (ha && hb) { couples.push_back(ca); couples.push_back(cb); }     // an even count in front keeps couples line-aligned
+                else if (ha) singles.push_back(ca);
+                else if (hb) singles.push_back(cb);
+            }
+            level = couples;
+            level.insert(level.end(), singles.begin(), singles.end());
+        }
+        if (order.size() > cap) return MIPT_ERR_SCENE_LIMIT;
+        for (size_t j = 0; j < order.size(); j++) order_out[j] = order[j];
+        *n_records_out = (uint32_t)order.size();
+        return MIPT_OK;
+    } catch (const std::exception &) {
+        return MIPT_ERR_INVALID_ARG;
+    }
+}

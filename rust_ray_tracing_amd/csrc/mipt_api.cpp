@@ -49,6 +49,7 @@ int fail(int code, const char *fmt, ...) {
 } // namespace
 
 void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);   // bvh_build.cpp
 
 struct MiptScene {
     int device = 0;
@@ -186,30 +187,20 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     for (uint32_t k = 0; k < n_pairs; k++) new_of[k] = k;
 #if !defined(MIPT_PAIR_LAYOUT) || MIPT_PAIR_LAYOUT != 0
     if (n_pairs > 0) {
-        std::vector<uint32_t> order;                                        // record index -> reference pair index (0xffffffff = pad)
-        order.reserve((size_t)n_pairs + 64);
+        std::vector<uint32_t> order(2 * (size_t)n_pairs + 2);               // record index -> reference pair index (0xffffffff = pad; at most one pad per level)
+        uint32_t n_records = 0;
+        {
+            const uint32_t cap = order.size() < (size_t)mipt::kMaxPairs ? (uint32_t)order.size() : mipt::kMaxPairs;
+            const int rc = mipt_internal_pair_order(desc->nodes, desc->n_nodes, order.data(), cap, &n_records);   // bvh_build.cpp
+            if (rc != MIPT_OK) return fail(rc, "pair records (with line padding) exceed the 2^24 device-format limit or the order buffer");
+        }
+        order.resize(n_records);
         auto child_pair = [&](uint32_t k, uint32_t w, uint32_t *out) -> bool {
             const MiptNode &n = desc->nodes[2 * k + 1 + w];
             if (n.num_tris != 0u) return false;
             *out = (n.first_tri_or_child - 1u) / 2u;
             return true;
         };
-        std::vector<uint32_t> level{0u}, couples, singles;
-        while (!level.empty()) {
-            if (order.size() & 1u) order.push_back(0xffffffffu);            // every level starts on a line boundary
-            for (uint32_t k : level) order.push_back(k);
-            couples.clear(); singles.clear();
-            for (uint32_t k : level) {
-                uint32_t ca = 0, cb = 0;
-                const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
-                if (ha && hb) { couples.push_back(ca); couples.push_back(cb); }     // an even count in front keeps couples line-aligned
-                else if (ha) singles.push_back(ca);
-                else if (hb) singles.push_back(cb);
-            }
-            level = couples;
-            level.insert(level.end(), singles.begin(), singles.end());
-        }
-        if (order.size() > (size_t)mipt::kMaxPairs) return fail(MIPT_ERR_SCENE_LIMIT, "%zu pair records exceed the 2^24 device-format limit", order.size());
         for (size_t j = 0; j < order.size(); j++) if (order[j] != 0xffffffffu) new_of[order[j]] = (uint32_t)j;
         std::vector<float4> re(order.size() * 4, make_float4(0, 0, 0, 0));
         for (size_t j = 0; j < order.size(); j++) {

@@ -14,6 +14,7 @@
 
 static std::string g_err;
 void mipt_internal_set_error(const char *m) { g_err = m ? m : ""; }
+extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);
 extern "C" void mipt_material_default(MiptMaterial *m) { memset(m, 0, sizeof *m); m->base_color = {0.8f, 0.8f, 0.8f}; m->base_color_tex_id = m->emission_tex_id = UINT32_MAX; }
 namespace mipt_png { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
 namespace mipt_jpeg { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
@@ -73,6 +74,18 @@ int main(int argc, char **argv) {
         std::vector<MiptNode> nodes(2 * n);
         uint32_t cnt = 0;
         if (mipt_bvh_build(t.data(), n, nodes.data(), 2 * n, &cnt, 4) != MIPT_OK || cnt == 0 || cnt > (uint32_t)(2 * n - 1 + (n == 1))) return 4;
+        {   // the device record order over the same tree (bvh_build.cpp): a permutation of the pairs plus line pads
+            std::vector<uint32_t> order((size_t)cnt + 2);
+            uint32_t n_rec = 0;
+            if (mipt_internal_pair_order(nodes.data(), cnt, order.data(), (uint32_t)order.size(), &n_rec) != MIPT_OK) return 7;
+            std::vector<char> seen((cnt - 1) / 2, 0);
+            for (uint32_t j = 0; j < n_rec; j++) {
+                if (order[j] == 0xffffffffu) continue;
+                if (order[j] >= seen.size() || seen[order[j]]) return 8;
+                seen[order[j]] = 1;
+            }
+            for (char c : seen) if (!c) return 9;
+        }
     }
     printf("sanitize_host ok: loader %d ok / %d rejected, png %d decoded / %d rejected, jpeg+tga+bmp %d decoded / %d rejected\n", ok, bad, decoded, rejected,
            jdecoded, jrejected);
