@@ -3,7 +3,10 @@
 (~10 M-triangle) BVH, 1/2/4/8 GPUs, with the roofline of the trace kernel and the CPU path timed beside it.
 
     python bench.py --gpus N --steps K --warmup W [--mode tiles|samples]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+        one process drives all N GPUs through the library's own multi-GPU entry (mipt_render_multi_device: scene replicas, a host
+        thread and an RCCL communicator per device, ONE ncclGather / ncclReduce per frame) -- the reference's single-process host model
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        one process per GPU, collectives through torch.distributed (backend nccl = RCCL)
 
 A "step" is one full frame of the hot path (scene replicated per GPU, inputs resident in HBM):
   --mode tiles (default; BASELINE config 4's split and the metric's configuration): every rank traces its share of the
@@ -57,10 +60,15 @@ def device_bytes(st: dict, n_pixels: int) -> int:
     return (64 * st["inner_steps"] + 64 * st["tri_tests"] + 128 * st["hits"] + 4 * st["texel_fetches"] + 12 * n_pixels)
 
 
+# everything that decides what the trace kernel executes and what it reads: the kernel, its math, the device layout built by
+# mipt_api.cpp and the order of the pair records (bvh_build.cpp: mipt_internal_pair_order)
+KERNEL_SOURCES = ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp", "bvh_build.cpp")
+
+
 def kernel_source_sha() -> str:
     """Identifies the trace kernel's source: a committed PMC summary is only quoted if it was measured on this source."""
     h = hashlib.sha256()
-    for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp"):
+    for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "rust_ray_tracing_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -73,24 +81,30 @@ def pmc_traffic(n_tris_requested, w, h, spp, depth, traversal, mode):
     Quoted only for the configuration AND kernel source it was measured on; otherwise (None, reason)."""
     if (n_tris_requested, w, h, spp, depth, traversal, mode) != (10_000_000, 1920, 1080, 8, 64, "culled", "tiles"):
         return None, "not the profiled configuration"
-    path = os.path.join(ROOT, "profiles", "r2_pmc_summary.csv")
-    try:
-        vals, meta = {}, {}
-        for line in open(path).read().splitlines():
-            if line.startswith("#"):
-                for kv in line[1:].split():
-                    if "=" in kv:
-                        k, v = kv.split("=", 1)
-                        meta[k] = v
+    why = "no PMC summary under profiles/"
+    for name in ("r3_pmc_summary.csv", "r2_pmc_summary.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            vals, meta = {}, {"file": f"profiles/{name}"}
+            for line in open(path).read().splitlines():
+                if line.startswith("#"):
+                    for kv in line[1:].split():
+                        if "=" in kv:
+                            k, v = kv.split("=", 1)
+                            meta[k] = v
+                    continue
+                parts = line.split(",")
+                if len(parts) >= 3 and parts[0] != "kernel":
+                    vals[parts[1]] = float(parts[2])
+            if meta.get("kernel_sha") != kernel_source_sha():
+                why = f"profiles/{name} was measured on kernel source {meta.get('kernel_sha')}, this is {kernel_source_sha()}"
                 continue
-            parts = line.split(",")
-            if len(parts) >= 3 and parts[0] != "kernel":
-                vals[parts[1]] = float(parts[2])
-        if meta.get("kernel_sha") != kernel_source_sha():
-            return None, f"profiles/r2_pmc_summary.csv was measured on kernel source {meta.get('kernel_sha')}, this is {kernel_source_sha()}"
-        return int(vals["TCC_EA0_RDREQ_sum"] * 128 + vals["WRITE_SIZE"] * 1024), meta
-    except Exception as e:  # noqa: BLE001
-        return None, f"no PMC summary: {e}"
+            return int(vals["TCC_EA0_RDREQ_sum"] * 128 + vals["WRITE_SIZE"] * 1024), meta
+        except Exception as e:  # noqa: BLE001
+            why = f"profiles/{name}: {e}"
+    return None, why
 
 
 def baseline_metric():
@@ -127,6 +141,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", choices=["tiles", "samples"], default="tiles")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from THIS process through mipt_render_multi (RCCL inside the library: the reference's "
+                         "one-process host model).  Implied when --gpus N > 1 is started without torch.distributed.run")
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -150,24 +167,45 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # ---- launch model ----
+    #  * one process per GPU: started by torch.distributed.run (RANK / WORLD_SIZE set), collectives through torch.distributed (RCCL);
+    #  * ONE process for all GPUs: `python bench.py --gpus N` as is (or --single-process): mipt_multi_create over N devices, every
+    #    frame ONE mipt_render_multi_device call -- a host thread per device, ncclCommInitAll communicators, one ncclGather /
+    #    ncclReduce, assemble kernel on device 0.  This is how the reference's single-threaded host (src/main.rs:46,
+    #    src/renderer.rs:50-63) would drive a node.  Nothing is re-launched or exec'd in either model.
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    single = args.single_process or (args.gpus > 1 and not launched)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if single:
+        if launched and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("bench.py: --single-process drives all GPUs from one process; do not start it under torch.distributed.run with more than one rank")
+        rank, world, local_rank = 0, args.gpus, 0
+    else:
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with torch.distributed.run --nproc-per-node N, "
+                             "or no launcher at all (one process then drives all N GPUs through mipt_render_multi)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X backend has no CPU fallback")
+    lib = rrt.load()
+    if single:
+        visible = int(lib.mipt_device_count())
+        if visible < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {max(visible, 0)} HIP device(s) visible")
     if args.dist_backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and not single:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
     on_host = args.dist_backend == "gloo"
+    multi_proc = world > 1 and not single
 
     def all_reduce_(t, op=dist.ReduceOp.SUM):
         if on_host:
@@ -176,7 +214,6 @@ def main():
             t.copy_(c)
         else:
             dist.all_reduce(t, op=op)
-    lib = rrt.load()
 
     # ---- scene (identical on every rank: seeded generator + deterministic builder) ----
     t0 = time.time()
@@ -187,20 +224,34 @@ def main():
     bvh_ms = scene.build_bvh_device(local_rank)        # identical tree to BVH::build (bvh.rs:13-161), tests/test_gpu_more.py
     t2 = time.time()
     scene.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
-    handle = scene.upload(local_rank)
+    if single:
+        multi = scene.upload_multi(list(range(world)))   # one replica + stream + RCCL communicator per device, uploads concurrent
+        handle = None
+    else:
+        multi = None
+        handle = scene.upload(local_rank)
     t3 = time.time()
-    log(rank, f"scene: {len(scene.tris)} tris, {len(scene.bvh_nodes)} nodes; gen {t1 - t0:.1f}s, device bvh {bvh_ms:.0f} ms ({t2 - t1:.1f}s with transfers), upload {t3 - t2:.1f}s")
+    log(rank, f"scene: {len(scene.tris)} tris, {len(scene.bvh_nodes)} nodes; gen {t1 - t0:.1f}s, device bvh {bvh_ms:.0f} ms ({t2 - t1:.1f}s with transfers), "
+              f"upload {t3 - t2:.1f}s" + (f" ({world} replicas, one process)" if single else ""))
 
     w, h, spp, depth = args.width, args.height, args.spp, args.depth
     trav = L.TRAVERSAL_CULLED if args.traversal == "culled" else L.TRAVERSAL_REFERENCE
     n_pix = w * h
     cam_ptr = L.ptr(scene.camera.uniform)
     stream = torch.cuda.current_stream(dev)
-    n_slot = int(lib.mipt_packed_pixels(w, h, world)) if world > 1 else n_pix
-    d_local = torch.empty(max(n_slot, n_pix) * 3, dtype=torch.float32, device=dev)
-    d_all = torch.empty(world * n_slot * 3, dtype=torch.float32, device=dev) if world > 1 else None
     d_frame = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+    if not single:
+        n_slot = int(lib.mipt_packed_pixels(w, h, world)) if world > 1 else n_pix
+        d_local = torch.empty(max(n_slot, n_pix) * 3, dtype=torch.float32, device=dev)
+        d_all = torch.empty(world * n_slot * 3, dtype=torch.float32, device=dev) if world > 1 else None
     s_begin, s_count = sharding.sample_ranges(spp, world)[rank]
+
+    def sync_devices():
+        if single:
+            for i in range(world):
+                torch.cuda.synchronize(i)
+        else:
+            torch.cuda.synchronize(dev)
 
     def render(mode, extra_flags=0, traversal=trav, out=None):
         """One launch of this rank's share in `mode`; returns MiptStats as a dict."""
@@ -216,7 +267,18 @@ def main():
                                        C.c_void_p(stream.cuda_stream), C.byref(st)), "mipt_render_device")
         return st.as_dict()
 
+    def render_node(mode, extra_flags=0):
+        """One frame on all devices through the library's own multi-GPU entry; the frame lands in d_frame (device 0)."""
+        opt = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM if mode == "tiles" else L.SEED_PER_SAMPLE, trav, extra_flags,
+                               cull_margin=L.CULL_MARGIN_SAFE)
+        st = L.MiptMultiStats()
+        L.check(lib.mipt_render_multi_device(multi, cam_ptr, C.byref(opt), L.MULTI_TILES if mode == "tiles" else L.MULTI_SAMPLES,
+                                             C.c_void_p(d_frame.data_ptr()), None, C.byref(st)), "mipt_render_multi_device")
+        return st.as_dict()
+
     def step(mode):
+        if single:
+            return render_node(mode)
         if mode == "samples" and s_count == 0:                      # more ranks than samples: this rank contributes zeros
             d_local.zero_()
             st = {"kernel_ms": 0.0}
@@ -247,8 +309,14 @@ def main():
             torch.div(part, float(spp), out=d_frame)                 # cpu.rs:60, once, on the reduced sum (rank 0's is the frame)
         return st
 
-    def measure(mode):
-        # counting build, outside the timed region (deterministic: same counts as the timed launches)
+    def count(mode):
+        """Counting build, outside the timed region (deterministic: same counts as the timed launches).
+        Returns (whole-job totals, the counts of rank 0's / device 0's own launch)."""
+        if single:
+            tot_st = render_node(mode, extra_flags=L.FLAG_COUNT)
+            d0 = L.MiptStats()
+            L.check(lib.mipt_multi_device_stats(multi, 0, C.byref(d0)), "mipt_multi_device_stats")
+            return {k: int(tot_st[k]) for k in COUNT_KEYS}, {k: int(getattr(d0, k)) for k in COUNT_KEYS}
         if mode == "samples" and s_count == 0:
             cst = {k: 0 for k in COUNT_KEYS}
         else:
@@ -257,34 +325,44 @@ def main():
         local_counts = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
         if world > 1:
             all_reduce_(counts)
-        tot = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
+        return {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}, local_counts
+
+    def measure(mode):
+        tot, local_counts = count(mode)
         want_pixels = n_pix if mode == "tiles" else n_pix * min(world, spp)
         assert tot["pixels"] == want_pixels, (tot["pixels"], want_pixels)
         for _ in range(args.warmup):
             step(mode)
-        if world > 1:
+        if multi_proc:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync_devices()
         t_start = time.perf_counter()
-        kernel_ms = []
+        steps_st = []
         for _ in range(args.steps):
-            kernel_ms.append(step(mode)["kernel_ms"])
-        if world > 1:
+            steps_st.append(step(mode))
+        if multi_proc:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync_devices()
         elapsed = time.perf_counter() - t_start
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi_proc:
+            el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             all_reduce_(el, op=dist.ReduceOp.MAX)
-        return float(el.item()), tot, local_counts, kernel_ms
+            elapsed = float(el.item())
+        return elapsed, tot, local_counts, steps_st
 
     mode = args.mode
-    elapsed, tot, local_counts, kernel_ms = measure(mode)
+    elapsed, tot, local_counts, steps_st = measure(mode)
     log(rank, f"{mode}: counts {tot}")
     value = tot["rays"] * args.steps / elapsed / 1e6
     frame_primary = d_frame.clone()
+    import zlib
+    frame_crc = zlib.crc32(frame_primary.cpu().numpy().tobytes()) & 0xFFFFFFFF     # identifies the frame across runs / launch models
 
-    # roofline of the dominant kernel (pt_trace_kernel), this rank's launches
+    # roofline of the dominant kernel (pt_trace_kernel): the launches of rank 0 (one process per GPU) / device 0 (one process)
+    if single:
+        kernel_ms = [st["device_kernel_ms"][0] for st in steps_st]
+    else:
+        kernel_ms = [st["kernel_ms"] for st in steps_st]
     avg_kernel_s = max(float(np.mean(kernel_ms)), 1e-9) * 1e-3
     n_local_samples = local_counts["pixels"] * (spp if mode == "tiles" else s_count)
     alg_bytes = algorithmic_bytes(local_counts, n_local_samples)
@@ -292,10 +370,15 @@ def main():
     achieved = alg_bytes / avg_kernel_s / 1e9
     traffic, prov = pmc_traffic(args.tris, w, h, spp, depth, args.traversal, mode) if world == 1 else (None, "N > 1")
     seeds = "pixel-stream seeds (cpu.rs:28-29)" if mode == "tiles" else "per-sample seeds (rt_compute.wgsl:102)"
+    how = ("one process, mipt_multi_create (ncclCommInitAll) + one mipt_render_multi_device call per frame" if single
+           else "one process per GPU over torch.distributed (RCCL)" if world > 1 else "one process, one GPU")
     if mode == "tiles":
-        shard = f"8x8 image tiles round-robin over {world} rank(s)" + (", one RCCL all-gather of packed tile slices per frame" if world > 1 else "")
+        shard = (f"8x8 image tiles round-robin over {world} GPU(s)"
+                 + ((", ONE ncclGather of rank-packed f32 tile slices to device 0 + de-interleave kernel per frame" if single else
+                     ", one RCCL all-gather of packed tile slices per frame") if world > 1 or single else "") + f"; {how}")
     else:
-        shard = f"{spp} samples split over {world} rank(s), every rank all pixels" + (", one RCCL sum-reduce of the f32 HDR sums per frame" if world > 1 else "")
+        shard = (f"{spp} samples split over {world} GPU(s), every GPU all pixels"
+                 + (", ONE ncclReduce(sum, f32) of the HDR sums to device 0 per frame" if world > 1 or single else "") + f"; {how}")
     result = {
         "metric": baseline_metric(),
         "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -304,29 +387,37 @@ def main():
         "config": {"workload": f"atrium stand-in for Intel Sponza + curtains: {len(scene.tris)} tris, {len(scene.bvh_nodes)} BVH nodes, "
                                f"{w}x{h}, {spp} spp, max_ray_depth {depth}, traversal {args.traversal}"
                                + (f" (margin {L.CULL_MARGIN_SAFE})" if args.traversal == "culled" else "") + f", {seeds}",
-                   "mode": mode, "sharding": shard, "rays_per_frame": tot["rays"], "paths_per_frame": n_pix * spp},
+                   "mode": mode, "sharding": shard, "launch": "single-process" if single else ("torch.distributed.run" if world > 1 else "single-gpu"),
+                   "rays_per_frame": tot["rays"], "paths_per_frame": n_pix * spp, "frame_crc32": f"{frame_crc:08x}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "basis": "ALGORITHMIC bytes in the reference's layouts (Node 32 B, Triangle 112 B, Material 80 B; SURVEY 8(d)) / kernel time. "
-                              "Not bytes moved: most are L1/L2 hits and the device layout is leaner -- see device_GBs (requested by the kernel's "
-                              "loads) and traffic (memory side, measured)",
+                              "A cache-side figure of merit that may exceed 1: most of these bytes are L1/L2 hits and the device layout is leaner -- "
+                              "see device_GBs (requested by the kernel's loads) and traffic / memside_frac_measured (memory side, measured)",
                      "traffic": traffic,
-                     "traffic_note": ("bytes per launch at the L2's memory side (HBM + Infinity Cache), rocprofv3 PMC in a separate run of this command: "
+                     "traffic_note": ("bytes per launch at the L2's memory side (HBM + Infinity Cache together), rocprofv3 PMC in a separate run of this command: "
                                       "TCC_EA0_RDREQ_sum x 128 B (every request is a 128-B line fill, calibrated for per-lane 64-B gathers in "
                                       "profiles/r2_fetch_calibration.csv) + WRITE_SIZE; provenance in traffic_provenance") if traffic else
                                      f"null: {prov}",
                      "traffic_provenance": prov if traffic else None,
-                     "hbm_frac_measured": round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                     "memside_frac_measured": round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                      "kernel": "pt_trace_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3), "kernel_source_sha": kernel_source_sha(),
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": round(alg_bytes / max(local_counts["rays"], 1), 1),
                      "device_bytes_per_launch": dev_bytes, "device_GBs": round(dev_bytes / avg_kernel_s / 1e9, 1),
                      "mray_s_kernel": round(local_counts["rays"] / avg_kernel_s / 1e6, 2)},
     }
+    if single:
+        result["single_process"] = {
+            "entry": "mipt_render_multi_device (frame stays on device 0; no D2H in the timed region)",
+            "device_kernel_ms": [round(float(np.mean([st["device_kernel_ms"][i] for st in steps_st])), 3) for i in range(world)],
+            "collective_ms": round(float(np.mean([st["collective_ms"] for st in steps_st])), 3),
+            "call_wall_ms": round(float(np.mean([st["wall_ms"] for st in steps_st])), 3)}
 
     # ---- N > 1: the other sharding mode, same steps (the tile split is floored by the per-pixel RNG chain; samples are not) ----
     if world > 1 and not args.no_other_mode:
         other = "samples" if mode == "tiles" else "tiles"
-        e2, tot2, _, k2 = measure(other)
+        e2, tot2, _, st2 = measure(other)
+        k2 = [st["device_kernel_ms"][0] for st in st2] if single else [st["kernel_ms"] for st in st2]
         result["other_mode"] = {"mode": other, "value": round(tot2["rays"] * args.steps / e2 / 1e6, 3), "unit": "Mray/s",
                                 "ms_per_step": round(e2 / args.steps * 1e3, 3), "rays_per_frame": tot2["rays"],
                                 "kernel_ms_rank0": round(float(np.mean(k2)), 3)}
@@ -335,27 +426,29 @@ def main():
     if rank == 0 and not args.no_parity:
         par = {"against": "oracle/pt_oracle.c = C restatement of the rayon CPU backend incl. its libm (glibc 2.35 cosf/log10f/powf restated, "
                           "== the host's libm on all 2^32 arguments: tests/test_libm_pin.py)"}
-        if world > 1 and mode == "tiles":
-            # the all-gathered + de-interleaved frame must equal a frame rendered by this rank alone, bit for bit
-            solo = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
-            opt1 = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM, trav, 0, 0, 1, cull_margin=L.CULL_MARGIN_SAFE)
-            L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt1), C.c_void_p(solo.data_ptr()), None,
-                                           C.c_void_p(stream.cuda_stream), None), "mipt_render_device")
+        if single:
+            handle = scene.upload(0)                  # a plain single-GPU replica next to the node handle, for the comparisons below
+
+        def solo_frame(seed_mode, traversal=trav):
+            """The whole frame rendered by ONE launch on this GPU (no sharding)."""
+            buf = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+            opt1 = rrt.make_options(w, h, spp, depth, seed_mode, traversal, 0, 0, 1, cull_margin=L.CULL_MARGIN_SAFE)
+            st1 = L.MiptStats()
+            L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt1), C.c_void_p(buf.data_ptr()), None,
+                                           C.c_void_p(stream.cuda_stream), C.byref(st1)), "mipt_render_device")
             torch.cuda.synchronize(dev)
+            return buf, st1.as_dict()
+        if (world > 1 or single) and mode == "tiles":
+            # the gathered + de-interleaved frame must equal a frame rendered by one GPU alone, bit for bit
+            solo, _ = solo_frame(L.SEED_PIXEL_STREAM)
             par["gathered_frame_equals_single_gpu_frame"] = bool(torch.equal(frame_primary.view(torch.int32), solo.view(torch.int32)))
             del solo
-        if world > 1 and mode == "samples":
-            solo = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
-            opt1 = rrt.make_options(w, h, spp, depth, L.SEED_PER_SAMPLE, trav, 0, cull_margin=L.CULL_MARGIN_SAFE)
-            L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt1), C.c_void_p(solo.data_ptr()), None,
-                                           C.c_void_p(stream.cuda_stream), None), "mipt_render_device")
-            torch.cuda.synchronize(dev)
+        if (world > 1 or single) and mode == "samples":
+            solo, _ = solo_frame(L.SEED_PER_SAMPLE)
             par["reduced_frame_max_rel_diff_vs_single_gpu"] = float(((frame_primary - solo).abs() / solo.abs().clamp_min(1e-6)).max().item())
             del solo
         if world == 1 and args.traversal == "culled" and mode == "tiles":
-            ref_buf = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
-            rst = render("tiles", traversal=L.TRAVERSAL_REFERENCE, out=ref_buf)
-            torch.cuda.synchronize(dev)
+            ref_buf, rst = solo_frame(L.SEED_PIXEL_STREAM, traversal=L.TRAVERSAL_REFERENCE)
             par["culled_equals_reference_traversal"] = bool(torch.equal(frame_primary.view(torch.int32), ref_buf.view(torch.int32)))
             # the headline uses the culled traversal (identical frame, re-checked above on every run); the CPU backend's own
             # un-culled traversal (ray.rs:69-81) on the same frame, one launch:
@@ -365,7 +458,7 @@ def main():
         result["parity"] = par
 
     # ---- N = 1: the in-library multi-GPU path (mipt_render_multi: RCCL communicator + gather / reduce behind the C ABI) ----
-    if rank == 0 and world == 1 and not args.no_render_multi:
+    if rank == 0 and world == 1 and not single and not args.no_render_multi:
         try:
             r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h), output_image_path="/dev/null",
                                                      traversal=trav, cull_margin=L.CULL_MARGIN_SAFE))
@@ -421,7 +514,7 @@ def main():
     sys.stdout.flush()
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
-    if world > 1:
+    if multi_proc:
         dist.barrier()
         dist.destroy_process_group()
 

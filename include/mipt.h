@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 2
+#define MIPT_ABI_VERSION 3
 
 /* ---- PODs, byte-identical to the reference's #[repr(C, align(16))] structs ---------- */
 typedef struct { float x, y, z; } MiptVec3;                 /* src/math/vec3.rs:55-59  (12 B) */
@@ -153,8 +153,8 @@ enum MiptStatus {
 /* ---- the seam ----------------------------------------------------------------------- */
 
 /* Copies the scene to HBM of HIP device `device_id`, re-basing the BVH into 64-byte child-pair
- * records and splitting triangles into a 48-byte intersection stream and a 64-byte shading
- * stream.  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
+ * records and splitting triangles into an intersection stream (36 B of payload at a 64-byte stride, so
+ * a record never straddles a 128-byte line) and a 64-byte shading stream.  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
 int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out);
 void mipt_scene_destroy(MiptScene *scene);
 
@@ -209,7 +209,7 @@ enum MiptMultiMode {
 typedef struct {
     MiptStats total;              /* counters summed over devices; kernel_ms = the slowest device's trace kernel */
     double    collective_ms;      /* gather/reduce + assemble (+ tonemap) on device 0's stream, HIP events */
-    double    wall_ms;            /* the whole call on the host clock, incl. the D2H copy of the outputs */
+    double    wall_ms;            /* the whole call on the host clock; mipt_render_multi: incl. the D2H copy of the outputs */
     double    device_kernel_ms[8];/* trace-kernel time of devices 0..7 */
     uint32_t  n_devices, reserved;
 } MiptMultiStats;
@@ -225,6 +225,17 @@ int  mipt_multi_device_count(const MiptMulti *multi);
  * flags must be 0 (the call owns the sharding); MIPT_FLAG_COUNT is honoured. */
 int  mipt_render_multi(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
                        float *hdr_rgb, uint8_t *rgba8, MiptMultiStats *stats);
+
+/* Same, but the frame stays in HBM: d_hdr_rgb (width*height*3 f32, required) and d_rgba8 (width*height*4 bytes, may be
+ * NULL) are buffers in the memory of the ROOT device (mipt_multi_root_device(): device_ids[0]); the assemble kernels write
+ * them directly and nothing crosses PCIe.  The multi-GPU counterpart of mipt_render_device. */
+int  mipt_render_multi_device(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
+                              float *d_hdr_rgb, uint8_t *d_rgba8, MiptMultiStats *stats);
+/* HIP ordinal of the device that gathers / reduces and holds the assembled frame, or a negative MiptStatus. */
+int  mipt_multi_root_device(const MiptMulti *multi);
+/* Trace-kernel stats of device `index` (0 .. mipt_multi_device_count()-1) in the last mipt_render_multi* call:
+ * MiptMultiStats.total sums the counters, this is one device's share (what its one launch did). */
+int  mipt_multi_device_stats(const MiptMulti *multi, int index, MiptStats *out);
 
 /* ---- host-side restatements of the scene model that feeds the path ------------------- */
 

@@ -10,6 +10,7 @@
 #include "mipt.h"
 
 #include <cstdio>
+#include <memory>
 #include <optional>
 #include <string>
 #include <utility>
@@ -86,6 +87,33 @@ class Scene {                                              // src/scene.rs:12-19
         return s;
     }
     void set_camera(const Camera &c) { camera = c; camera.update_view(); }   // src/scene.rs:38-41
+
+    // Device residency for Renderer::render_node: the per-device replicas, streams and RCCL communicators (MiptMulti) are
+    // created on first use and kept -- like the wgpu backend's State, built once in State::new (gpu.rs:96-118) -- so a
+    // second frame costs no upload and no ncclCommInitAll.  Call release_device() after changing tris / bvh_nodes /
+    // materials / textures (the camera is passed per frame and needs no re-upload).
+    void release_device() const { multi_.reset(); multi_devices_ = -1; }
+    MiptMulti *node_handle(int n_devices) const {
+        if (multi_ && multi_devices_ == n_devices) return multi_.get();
+        release_device();
+        std::vector<MiptMaterial> mats;
+        for (const auto &kv : materials) mats.push_back(kv.second);
+        std::vector<MiptTexture> texs;
+        for (const Texture &t : textures) texs.push_back({t.width, t.height, t.pixel_data.data()});
+        MiptSceneDesc d{tris.data(), (uint32_t)tris.size(), bvh_nodes.data(), (uint32_t)bvh_nodes.size(),
+                        mats.data(), (uint32_t)mats.size(), texs.data(), (uint32_t)texs.size()};
+        MiptMulti *m = nullptr;
+        if (mipt_multi_create(&d, nullptr, n_devices, &m) != MIPT_OK) { log_error(mipt_last_error()); return nullptr; }
+        multi_ = std::shared_ptr<MiptMulti>(m, [](MiptMulti *p) { mipt_multi_destroy(p); });
+        multi_devices_ = n_devices;
+        return m;
+    }
+
+  private:
+    mutable std::shared_ptr<MiptMulti> multi_;
+    mutable int multi_devices_ = -1;
+
+  public:
     void build_bvh(uint32_t threads = 0) {                 // BVH::build (src/bvh.rs:13-54)
         bvh_nodes.resize(tris.empty() ? 1 : 2 * tris.size());
         uint32_t n = 0;
@@ -143,21 +171,14 @@ class Renderer {                                           // src/renderer.rs:8-
     // render()'s bytes exactly; MIPT_MULTI_SAMPLES uses the wgpu shader's per-sample seeds (rt_compute.wgsl:102).
     std::vector<uint8_t> render_node(const Scene &scene, uint32_t mode = MIPT_MULTI_TILES, int n_devices = 0) const {
         if (options.backend != RendererBackend::MI355X) { log_error("this build only provides RendererBackend::MI355X"); return {}; }
-        std::vector<MiptMaterial> mats;
-        for (const auto &kv : scene.materials) mats.push_back(kv.second);
-        std::vector<MiptTexture> texs;
-        for (const Texture &t : scene.textures) texs.push_back({t.width, t.height, t.pixel_data.data()});
-        MiptSceneDesc d{scene.tris.data(), (uint32_t)scene.tris.size(), scene.bvh_nodes.data(), (uint32_t)scene.bvh_nodes.size(),
-                        mats.data(), (uint32_t)mats.size(), texs.data(), (uint32_t)texs.size()};
-        MiptMulti *m = nullptr;
-        if (mipt_multi_create(&d, nullptr, n_devices, &m) != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        MiptMulti *m = scene.node_handle(n_devices);                       // cached in the Scene: created on the first frame only
+        if (!m) return {};
         MiptOptions o{};
         o.width = (uint32_t)options.output_image_dimensions.first; o.height = (uint32_t)options.output_image_dimensions.second;
         o.samples = (uint32_t)options.samples; o.max_ray_depth = (uint32_t)options.max_ray_depth;
         o.traversal = options.traversal; o.cull_margin = MIPT_CULL_MARGIN_SAFE;
         std::vector<uint8_t> out((size_t)o.width * o.height * 4);
         const int rc = mipt_render_multi(m, &scene.camera.uniform, &o, mode, nullptr, out.data(), nullptr);
-        mipt_multi_destroy(m);
         if (rc != MIPT_OK) { log_error(mipt_last_error()); return {}; }
         return out;
     }

@@ -87,6 +87,7 @@ EXPORTS = [
     "mipt_device_count", "mipt_obj_load", "mipt_obj_free", "mipt_obj_get",
     "mipt_texture_load", "mipt_texture_free", "mipt_image_save_png",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_render_multi",
+    "mipt_render_multi_device", "mipt_multi_root_device", "mipt_multi_device_stats",
 ]
 
 _lib = None
@@ -158,6 +159,12 @@ def load() -> C.CDLL:
     lib.mipt_multi_device_count.restype = C.c_int
     lib.mipt_render_multi.argtypes = [vp, vp, C.POINTER(MiptOptions), u32, vp, vp, C.POINTER(MiptMultiStats)]
     lib.mipt_render_multi.restype = C.c_int
+    lib.mipt_render_multi_device.argtypes = [vp, vp, C.POINTER(MiptOptions), u32, vp, vp, C.POINTER(MiptMultiStats)]
+    lib.mipt_render_multi_device.restype = C.c_int
+    lib.mipt_multi_root_device.argtypes = [vp]
+    lib.mipt_multi_root_device.restype = C.c_int
+    lib.mipt_multi_device_stats.argtypes = [vp, C.c_int, C.POINTER(MiptStats)]
+    lib.mipt_multi_device_stats.restype = C.c_int
     _lib = lib
     return lib
 

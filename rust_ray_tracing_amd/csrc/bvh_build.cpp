@@ -287,6 +287,7 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         if (n_pairs > 0) level.push_back(0u);
         while (!level.empty()) {
             if (order.size() & 1u) order.push_back(0xffffffffu);            // every level starts on a line boundary
+            if (order.size() + level.size() > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;   // also bounds a malformed (shared-child) input
             for (uint32_t k : level) order.push_back(k);
             couples.clear(); singles.clear();
             for (uint32_t k : level) {

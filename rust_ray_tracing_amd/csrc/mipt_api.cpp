@@ -141,6 +141,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     // ---- validate and re-base the BVH: pair[k] = {nodes[2k+1], nodes[2k+2]} ----
     uint32_t max_leaf = 0;
     uint32_t tiny_axes = 0;
+    std::vector<uint8_t> pair_seen(n_pairs, 0);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const MiptNode &n = desc->nodes[i];
         {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused); axes on which some
@@ -162,8 +163,14 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             const uint32_t c = n.first_tri_or_child;
             if ((c & 1u) == 0u || (uint64_t)c + 1u >= desc->n_nodes || c <= i)
                 return fail(MIPT_ERR_BVH, "inner node %u has child index %u (must be odd, > parent, and c+1 < n_nodes=%u)", i, c, desc->n_nodes);
+            // a tree, not a DAG: BVH::split_node pushes every child pair once (bvh.rs:115-132).  Two inner nodes sharing a pair
+            // would make the breadth-first record order below grow exponentially with depth.
+            if (pair_seen[(c - 1u) / 2u]) return fail(MIPT_ERR_BVH, "child pair at node %u is referenced by more than one inner node (node %u is the second)", c, i);
+            pair_seen[(c - 1u) / 2u] = 1;
         }
     }
+    for (uint32_t k = 0; k < n_pairs; k++)
+        if (!pair_seen[k]) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * k + 1, 2 * k + 2);
     std::vector<float4> pairs((size_t)n_pairs * 4);
     for (uint32_t k = 0; k < n_pairs; k++) {
         for (uint32_t w = 0; w < 2; w++) {
@@ -374,9 +381,18 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     std::vector<std::string> errs((size_t)n_dev);
     {
         std::vector<std::thread> th;
-        for (int i = 0; i < n_dev; i++)
-            th.emplace_back([&, i] { rcs[(size_t)i] = upload_to(device_ids[i], &outs[i]); if (rcs[(size_t)i]) errs[(size_t)i] = g_err; });
+        th.reserve((size_t)n_dev);
+        auto work = [&](int i) { rcs[(size_t)i] = upload_to(device_ids[i], &outs[i]); if (rcs[(size_t)i]) errs[(size_t)i] = g_err; };
+        bool spawn_failed = false;
+        try {                                                       // a throwing std::thread constructor must not unwind past joinable threads
+            for (int i = 1; i < n_dev; i++) th.emplace_back(work, i);
+        } catch (const std::exception &) { spawn_failed = true; }
+        if (!spawn_failed) work(0);
         for (auto &t : th) t.join();
+        if (spawn_failed) {
+            for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
+            return fail(MIPT_ERR_HIP, "mipt_multi_create: could not start a host thread per device");
+        }
     }
     for (int i = 0; i < n_dev; i++)
         if (rcs[(size_t)i]) {

@@ -43,6 +43,7 @@ struct MiptMulti {
     uint8_t *d_rgba = nullptr;
     size_t rgba_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<MiptStats> last;          // per device: trace-kernel stats of the last mipt_render_multi* call
 };
 
 namespace {
@@ -111,6 +112,7 @@ int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices,
     m->streams.assign(n_devices, nullptr);
     m->d_part.assign(n_devices, nullptr);
     m->part_floats.assign(n_devices, 0);
+    m->last.assign(n_devices, MiptStats{});
     // scene replicas: the device layout is built once on the host, the uploads run concurrently (one host thread per device)
     {
         const int rc = mipt_scene_create_replicas(desc, m->devices.data(), n_devices, m->scenes.data());
@@ -130,9 +132,21 @@ int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices,
     return MIPT_OK;
 }
 
+// Every stream of `m` drained, errors ignored: after a failure between ncclGroupStart and the final synchronisation the other
+// ranks' streams may still hold their part of the collective, and the next call reuses d_part / d_all.
+void drain(MiptMulti *m) {
+    for (int i = 0; i < m->n; i++) {
+        if (hipSetDevice(m->devices[i]) == hipSuccess && m->streams[i]) (void)hipStreamSynchronize(m->streams[i]);
+    }
+    (void)hipSetDevice(m->devices[0]);
+}
+
+// device_out: hdr_rgb / rgba8 are buffers in DEVICE 0's memory (mipt_render_multi_device) -- the assemble kernels write them
+// directly and nothing is copied to the host; otherwise host buffers (mipt_render_multi).
 int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode, float *hdr_rgb, uint8_t *rgba8,
-                MiptMultiStats *stats) {
+                MiptMultiStats *stats, bool device_out) {
     if (!m || !camera || !opt) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_multi: null argument");
+    if (device_out && !hdr_rgb) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_multi_device: d_hdr_rgb == NULL");
     if (mode > MIPT_MULTI_SAMPLES) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_multi: unknown mode");
     if (opt->tile_rank || opt->tile_world > 1 || opt->sample_begin > 1 ||
         (opt->flags & (MIPT_FLAG_PACKED | MIPT_FLAG_SUM | MIPT_FLAG_ACCUM)))
@@ -158,11 +172,15 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
         int rc = grow((void **)&m->d_all, &have, (mode == MIPT_MULTI_TILES ? (size_t)n * part_floats : 4) * sizeof(float));
         if (rc) return rc;
         m->all_floats = have / sizeof(float);
-        have = m->frame_floats * sizeof(float);
-        if ((rc = grow((void **)&m->d_frame, &have, (size_t)n_pix * 3 * sizeof(float)))) return rc;
-        m->frame_floats = have / sizeof(float);
-        if (rgba8 && (rc = grow((void **)&m->d_rgba, &m->rgba_bytes, (size_t)n_pix * 4))) return rc;
+        if (!device_out) {
+            have = m->frame_floats * sizeof(float);
+            if ((rc = grow((void **)&m->d_frame, &have, (size_t)n_pix * 3 * sizeof(float)))) return rc;
+            m->frame_floats = have / sizeof(float);
+            if (rgba8 && (rc = grow((void **)&m->d_rgba, &m->rgba_bytes, (size_t)n_pix * 4))) return rc;
+        }
     }
+    float *const d_frame = device_out ? hdr_rgb : m->d_frame;       // where the assembled frame is built (device 0)
+    uint8_t *const d_rgba = device_out ? rgba8 : m->d_rgba;
 
     // ---- per-device options ----
     std::vector<MiptOptions> opts(n, *opt);
@@ -191,10 +209,11 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     std::vector<MiptStats> st(n);
+    bool spawn_failed = false;
     {
         std::vector<std::thread> th;
-        for (int i = 0; i < n; i++)
-            th.emplace_back([&, i] {
+        th.reserve((size_t)n);
+        auto work = [&](int i) {
                 memset(&st[i], 0, sizeof(MiptStats));
                 if (share[i] == 0) {                                      // more devices than samples: contributes zeros
                     hipError_t e = hipSetDevice(m->devices[i]);
@@ -205,9 +224,16 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
                 }
                 rcs[i] = mipt_render_device_impl(m->scenes[i], camera, &opts[i], m->d_part[i], nullptr, (void *)m->streams[i], &st[i], true);
                 if (rcs[i]) errs[i] = mipt_last_error();
-            });
+        };
+        // a std::thread constructor that throws (EAGAIN) must not unwind past joinable threads: join what was started
+        try {
+            for (int i = 1; i < n; i++) th.emplace_back(work, i);
+        } catch (const std::exception &) { spawn_failed = true; }
+        if (!spawn_failed) work(0);                                       // device 0 on the calling thread
         for (auto &t : th) t.join();
     }
+    for (int i = 0; i < n; i++) m->last[i] = st[i];
+    if (spawn_failed) return fail(MIPT_ERR_HIP, "mipt_render_multi: could not start a host thread per device");
     int soft = MIPT_OK;                                                   // MIPT_ERR_STACK: frame incomplete but delivered, like mipt_render
     for (int i = 0; i < n; i++) {
         if (rcs[i] == MIPT_ERR_STACK) { soft = MIPT_ERR_STACK; continue; }
@@ -215,31 +241,42 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
     }
 
     // ---- the one collective, then assemble on device 0 ----
+    // From here on every rank's stream may hold work that touches d_part / d_all: any failure drains all streams before returning.
+#define M_HIP_D(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess) { drain(m); return fail(MIPT_ERR_HIP, std::string(#expr " failed: ") + hipGetErrorString(e__)); } \
+    } while (0)
     M_HIP(hipSetDevice(m->devices[0]));
     M_HIP(hipEventRecord(m->ev0, m->streams[0]));
-    M_NCCL(ncclGroupStart());
-    for (int i = 0; i < n; i++) {
-        ncclResult_t r;
-        if (mode == MIPT_MULTI_TILES)
-            r = ncclGather(m->d_part[i], i == 0 ? m->d_all : nullptr, part_floats, ncclFloat, 0, m->comms[i], m->streams[i]);
-        else
-            r = ncclReduce(m->d_part[i], i == 0 ? m->d_frame : nullptr, part_floats, ncclFloat, ncclSum, 0, m->comms[i], m->streams[i]);
-        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(MIPT_ERR_RCCL, std::string("RCCL collective failed: ") + ncclGetErrorString(r)); }
+    {
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; i++) {
+            if (mode == MIPT_MULTI_TILES)
+                r = ncclGather(m->d_part[i], i == 0 ? m->d_all : nullptr, part_floats, ncclFloat, 0, m->comms[i], m->streams[i]);
+            else
+                r = ncclReduce(m->d_part[i], i == 0 ? d_frame : nullptr, part_floats, ncclFloat, ncclSum, 0, m->comms[i], m->streams[i]);
+        }
+        const ncclResult_t r_end = ncclGroupEnd();
+        if (r == ncclSuccess) r = r_end;
+        if (r != ncclSuccess) { drain(m); return fail(MIPT_ERR_RCCL, std::string("RCCL collective failed: ") + ncclGetErrorString(r)); }
     }
-    M_NCCL(ncclGroupEnd());
-    M_HIP(hipSetDevice(m->devices[0]));
+    M_HIP_D(hipSetDevice(m->devices[0]));
     if (mode == MIPT_MULTI_TILES)
-        M_HIP(mipt::launch_unpack_tiles(m->d_all, opt->width, opt->height, (uint32_t)n, m->d_frame, m->streams[0]));
+        M_HIP_D(mipt::launch_unpack_tiles(m->d_all, opt->width, opt->height, (uint32_t)n, d_frame, m->streams[0]));
     else
-        M_HIP(mipt::launch_divide(m->d_frame, (unsigned long long)n_pix * 3, (float)opt->samples, m->streams[0]));   // cpu.rs:60
-    if (rgba8) M_HIP(mipt::launch_tonemap(m->d_frame, (unsigned long long)n_pix, 1.0f, m->d_rgba, m->streams[0]));
-    M_HIP(hipEventRecord(m->ev1, m->streams[0]));
-    if (hdr_rgb) M_HIP(hipMemcpyAsync(hdr_rgb, m->d_frame, (size_t)n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, m->streams[0]));
-    if (rgba8) M_HIP(hipMemcpyAsync(rgba8, m->d_rgba, (size_t)n_pix * 4, hipMemcpyDeviceToHost, m->streams[0]));
-    for (int i = n - 1; i >= 0; i--) {                                    // every rank's part of the collective has drained
-        M_HIP(hipSetDevice(m->devices[i]));
-        M_HIP(hipStreamSynchronize(m->streams[i]));
+        M_HIP_D(mipt::launch_divide(d_frame, (unsigned long long)n_pix * 3, (float)opt->samples, m->streams[0]));   // cpu.rs:60
+    if (rgba8) M_HIP_D(mipt::launch_tonemap(d_frame, (unsigned long long)n_pix, 1.0f, d_rgba, m->streams[0]));
+    M_HIP_D(hipEventRecord(m->ev1, m->streams[0]));
+    if (!device_out) {
+        if (hdr_rgb) M_HIP_D(hipMemcpyAsync(hdr_rgb, d_frame, (size_t)n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, m->streams[0]));
+        if (rgba8) M_HIP_D(hipMemcpyAsync(rgba8, d_rgba, (size_t)n_pix * 4, hipMemcpyDeviceToHost, m->streams[0]));
     }
+    for (int i = n - 1; i >= 0; i--) {                                    // every rank's part of the collective has drained
+        M_HIP_D(hipSetDevice(m->devices[i]));
+        M_HIP_D(hipStreamSynchronize(m->streams[i]));
+    }
+#undef M_HIP_D
     for (int i = 0; i < n; i++) {
         ncclResult_t async_err = ncclSuccess;
         M_NCCL(ncclCommGetAsyncError(m->comms[i], &async_err));
@@ -281,8 +318,22 @@ int mipt_multi_device_count(const MiptMulti *m) { return m ? m->n : 0; }
 
 int mipt_render_multi(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
                       float *hdr_rgb, uint8_t *rgba8, MiptMultiStats *stats) {
-    try { return render_impl(m, camera, opt, mode, hdr_rgb, rgba8, stats); }
+    try { return render_impl(m, camera, opt, mode, hdr_rgb, rgba8, stats, false); }
     catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, std::string("internal error: ") + e.what()); }
 }
+
+int mipt_render_multi_device(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
+                             float *d_hdr_rgb, uint8_t *d_rgba8, MiptMultiStats *stats) {
+    try { return render_impl(m, camera, opt, mode, d_hdr_rgb, d_rgba8, stats, true); }
+    catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, std::string("internal error: ") + e.what()); }
+}
+
+int mipt_multi_device_stats(const MiptMulti *m, int index, MiptStats *out) {
+    if (!m || !out || index < 0 || index >= m->n) return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_device_stats: bad argument");
+    *out = m->last[(size_t)index];
+    return MIPT_OK;
+}
+
+int mipt_multi_root_device(const MiptMulti *m) { return m ? m->devices[0] : MIPT_ERR_INVALID_ARG; }
 
 } // extern "C"

@@ -566,6 +566,11 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
             const bool phase = leaf_wait == 0u || m_in == 0ull || (uint32_t)__popcll(m_lf) * pr.leaf_den >= n_t;
             leaf_wait = phase ? pr.leaf_period - 1u : leaf_wait - 1u;
             leaf_hold = !phase;
+            if (COUNT) {                                     // wave-occupancy diagnostics (MiptStats.diag[0..4]); lane 0's copy is reported
+                g_iters++;
+                g_inner += (unsigned long long)__popcll(m_in); g_it_inner += (m_in != 0ull) ? 1u : 0u;
+                g_leaf += phase ? (unsigned long long)__popcll(m_lf) : 0ull; g_it_leaf += (phase && m_lf != 0ull) ? 1u : 0u;
+            }
         }
         if (state == ST_T && !(leaf_hold && tri_cur < tri_end)) {
             const bool leaf = tri_cur < tri_end;

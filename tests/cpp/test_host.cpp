@@ -59,6 +59,10 @@ int main(int argc, char **argv) {
     CHECK(want.size() == px.size() && memcmp(want.data(), px.data(), px.size()) == 0);
     const std::vector<uint8_t> px_node = r->render_node(*scene);                     // all GPUs of the node, one call (RCCL inside)
     CHECK(px_node.size() == px.size() && memcmp(px_node.data(), px.data(), px.size()) == 0);
+    MiptMulti *kept = scene->node_handle(0);                                         // replicas + communicators are cached in the Scene ...
+    const std::vector<uint8_t> px_node2 = r->render_node(*scene);                    // ... so a second frame re-uses them
+    CHECK(scene->node_handle(0) == kept && px_node2 == px_node);
+    scene->release_device();
     printf("host mirror (gpu) ok: config 1 RGBA8 identical to the oracle\n");
     return 0;
 }

@@ -62,3 +62,42 @@ def test_bench_two_ranks_rehearsal(built, mode):
         assert r["parity"]["gathered_frame_equals_single_gpu_frame"] is True
     else:
         assert r["parity"]["reduced_frame_max_rel_diff_vs_single_gpu"] < 1e-5
+
+
+MID = ["--tris", "300000", "--width", "960", "--height", "540", "--spp", "4", "--depth", "16", "--steps", "6", "--warmup", "2",
+       "--no-cpu-baseline", "--tex-size", "64"]
+
+
+@pytest.mark.gpu
+def test_bench_single_process_entry(built):
+    """`bench.py --gpus 1 --single-process`: the one-process launch model (mipt_multi_create + one mipt_render_multi_device call per
+    frame -- what `python bench.py --gpus 8` uses when started without torch.distributed.run) with a one-rank communicator.
+    Same frame as the plain N = 1 line; the rate within 10 % of it at this size (a 5 ms frame: the host thread hand-off, gather and
+    de-interleave are ~0.3 ms; at the bench size of 75 ms the two lines agree within 2 %, profiles/r3_bench_single_process.json)."""
+    plain = _run([sys.executable, os.path.join(ROOT, "bench.py")] + MID)
+    one = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-process"] + MID)
+    assert one["n_gpus"] == 1 and one["config"]["launch"] == "single-process" and plain["config"]["launch"] == "single-gpu"
+    assert one["config"]["frame_crc32"] == plain["config"]["frame_crc32"]
+    assert one["config"]["rays_per_frame"] == plain["config"]["rays_per_frame"]
+    assert one["parity"]["gathered_frame_equals_single_gpu_frame"] is True
+    sp = one["single_process"]
+    assert len(sp["device_kernel_ms"]) == 1 and sp["collective_ms"] > 0 and sp["call_wall_ms"] >= sp["device_kernel_ms"][0]
+    assert "ncclGather" in one["config"]["sharding"]
+    assert abs(one["value"] / plain["value"] - 1.0) < 0.10, (one["value"], plain["value"])
+    for k in ("achieved", "frac", "kernel_ms", "algorithmic_bytes_per_launch"):
+        assert one["roofline"][k] > 0
+
+
+@pytest.mark.gpu
+def test_bench_more_gpus_than_visible_fails_with_a_message(built, rrt):
+    n = rrt.load().mipt_device_count()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)] + SMALL, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert f"--gpus {n + 1} but only {n} HIP device(s) visible" in out.stderr and "Traceback" not in out.stderr
+
+
+def test_bench_rejects_a_world_size_that_is_not_gpus():
+    """CPU: WORLD_SIZE / --gpus mismatch is an error before anything touches a GPU (it was silently accepted)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and "Traceback" not in out.stderr and out.stdout.strip() == ""

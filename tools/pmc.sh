@@ -29,7 +29,7 @@ agg = collections.defaultdict(list)
 for n, v in rows: agg[n].append(v)
 import hashlib
 h = hashlib.sha256()
-for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp"):
+for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp", "bvh_build.cpp"):
     h.update(open(os.path.join("rust_ray_tracing_amd", "csrc", f), "rb").read())
 with open(out + "/pmc_summary.csv", "w") as f:
     f.write(f"# kernel_sha={h.hexdigest()[:16]} date={datetime.date.today().isoformat()} tool=tools/pmc.sh command=bench.py--steps2--warmup0{extra.replace(' ', '')}\n")
