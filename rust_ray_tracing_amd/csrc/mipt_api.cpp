@@ -54,7 +54,7 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
 struct MiptScene {
     int device = 0;
     mipt::DevScene dev{};
-    void *d_geom = nullptr, *d_top = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_mats_full = nullptr,
+    void *d_geom = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_mats_full = nullptr,
          *d_texels = nullptr;
     // workspace
     mipt::DevStats *d_stats = nullptr;
@@ -74,7 +74,7 @@ namespace {
 void free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_geom, s->d_top, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels,
+    void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels,
                     s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -290,36 +290,6 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     for (uint32_t i = 0; i < desc->n_textures; i++)
         memcpy(texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
 
-    // tree top in BFS order for the LDS staging experiment: pair k's children that are cached get (kTopFlag | slot)
-    std::vector<float4> top;
-    uint32_t n_top = 0;
-    {
-        std::vector<uint32_t> order;                     // global pair index per slot
-        std::vector<int32_t> slot_of(n_pairs, -1);
-        auto cacheable = [&](uint32_t k) {               // pairs with a >= 64-triangle leaf child use the child-ref stack form: keep global
-            return desc->nodes[2 * k + 1].num_tris < 64u && desc->nodes[2 * k + 2].num_tris < 64u;
-        };
-        if (n_pairs > 0 && cacheable(0)) { order.push_back(0); slot_of[0] = 0; }
-        for (size_t head = 0; head < order.size() && order.size() < (size_t)mipt::kTopPairs; head++) {
-            const uint32_t k = order[head];
-            for (uint32_t w = 0; w < 2 && order.size() < (size_t)mipt::kTopPairs; w++) {
-                const MiptNode &n = desc->nodes[2 * k + 1 + w];
-                if (n.num_tris == 0) { const uint32_t c = (n.first_tri_or_child - 1u) / 2u; if (cacheable(c)) { slot_of[c] = (int32_t)order.size(); order.push_back(c); } }
-            }
-        }
-        n_top = (uint32_t)order.size();
-        top.resize((size_t)mipt::kTopPairs * 4, make_float4(0, 0, 0, 0));
-        for (uint32_t s_i = 0; s_i < n_top; s_i++) {
-            for (int q = 0; q < 4; q++) top[(size_t)s_i * 4 + q] = pairs[(size_t)new_of[order[s_i]] * 4 + q];
-            for (uint32_t w = 0; w < 2; w++) {
-                const MiptNode &n = desc->nodes[2 * order[s_i] + 1 + w];
-                if (n.num_tris == 0) {
-                    const uint32_t c = (n.first_tri_or_child - 1u) / 2u;
-                    if (slot_of[c] >= 0) { const uint32_t ref = mipt::kTopFlag | (uint32_t)slot_of[c]; memcpy(&top[(size_t)s_i * 4 + w * 2].w, &ref, 4); }
-                }
-            }
-        }
-    }
     if (desc->nodes[0].num_tris == 0 && desc->nodes[0].first_tri_or_child != 1u)
         return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)");
     // pairs and tri_pos share one allocation (one buffer descriptor, 32-bit offsets in the kernel)
@@ -344,7 +314,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         if (e1 == hipSuccess) e1 = hipMemcpy((char *)s->d_geom + pairs_bytes, tri_pos.data(), pos_bytes, hipMemcpyHostToDevice);
         if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
     }
-    if ((rc = upload(&s->d_top, top, 64)) || (rc = upload(&s->d_tri_attr, tri_attr)) ||
+    if ((rc = upload(&s->d_tri_attr, tri_attr)) ||
         (rc = upload(&s->d_mats, mats, 64)) || (rc = upload(&s->d_mats_full, mats_full, 128)) || (rc = upload(&s->d_texels, texels, 16))) {
         free_scene(s);
         return rc;
@@ -362,8 +332,6 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     s->dev.tri_pos = (const float4 *)((const char *)s->d_geom + pairs_bytes);
     s->dev.tri_off_bytes = (uint32_t)pairs_bytes;
     s->dev.geom_bytes = (uint32_t)(pairs_bytes + pos_bytes);
-    s->dev.top = (const float4 *)s->d_top;
-    s->dev.n_top = n_top;
     s->dev.tiny_axes = tiny_axes;
     s->dev.tri_attr = (const float4 *)s->d_tri_attr;
     s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
@@ -485,9 +453,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     pr.samples_f = (float)opt->samples;                       // cpu.rs:60
     pr.cull_scale = 1.0f + opt->cull_margin;
     pr.service_num = 3; pr.service_den = 8; pr.reverse_tiles = 0;   // service pass when >= 3/8 of the live lanes wait for one (tools/sweep_service.py)
-    pr.lds_top = 0;
 #ifdef MIPT_TUNING   // experiment knobs exist only in a `make TUNING=1` build (tools/README.md); the product reads no environment
-    if (const char *e = getenv("MIPT_LDS_TOP")) pr.lds_top = atoi(e) ? 1u : 0u;
     if (const char *e = getenv("MIPT_REVERSE_TILES")) pr.reverse_tiles = atoi(e) ? 1u : 0u;
     if (const char *e = getenv("MIPT_SERVICE_NUM")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_num = (uint32_t)v; }
     if (const char *e = getenv("MIPT_SERVICE_DEN")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_den = (uint32_t)v; }
@@ -500,7 +466,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
 
     const bool count = (opt->flags & MIPT_FLAG_COUNT) != 0;
     const bool cull = opt->traversal == MIPT_TRAVERSAL_CULLED;
-    const int occ = mipt::trace_blocks_per_cu(count, cull, pr.lds_top != 0 && scene->dev.n_top > 0 && opt->shading == 0, (int)opt->shading);
+    const int occ = mipt::trace_blocks_per_cu(count, cull, (int)opt->shading);
     int bpc = occ;
     // Small shards (multi-GPU tile split: fewer pixels than resident lanes) are bound by the longest per-pixel chain --
     // a pixel's samples are sequential on one RNG stream -- and each chain steps faster with fewer co-resident waves:
@@ -534,7 +500,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
 
     HIP_TRY(hipMemsetAsync(scene->d_stats, 0, sizeof(mipt::DevStats), stream));
     HIP_TRY(hipEventRecord(scene->ev0, stream));
-    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, pr.lds_top != 0 && scene->dev.n_top > 0 && opt->shading == 0, (int)opt->shading, (int)grid, stream));
+    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, (int)opt->shading, (int)grid, stream));
     HIP_TRY(hipEventRecord(scene->ev1, stream));
     if (d_rgba8) HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, (unsigned long long)opt->width * opt->height, 1.0f, d_rgba8, stream));
     mipt::DevStats hs;

@@ -39,8 +39,6 @@ struct DevScene {
     const float4 *pairs;          // = geom: [pairs | tri_pos] live in ONE allocation so the traversal step can address either
     const float4 *tri_pos;        //   through one buffer descriptor with a 32-bit byte offset (tri_off_bytes = n_pairs * 64)
     uint32_t tri_off_bytes, geom_bytes;
-    const float4 *top;            // experiment: the first kTopPairs pairs in BFS order, child refs to cached pairs flagged (bit 30)
-    uint32_t n_top;
     uint32_t tiny_axes;           // bit c: some bounding plane has a coordinate 0 < |p_c| < 2^-76 on axis c (see ray_safe, pt_kernel.hip)
     const float4 *tri_attr;
     const DevMaterial *mats;
@@ -71,7 +69,6 @@ struct DevParams {
     float samples_f;
     float cull_scale;                       // 1 + cull_margin
     uint32_t reverse_tiles;                 // hand out the tile list back to front (bottom rows first)
-    uint32_t lds_top;                       // experiment: serve the first kTopPairs pairs from LDS
     uint32_t service_num, service_den;      // run the service pass when need/live >= num/den
     uint32_t leaf_period, leaf_den;         // triangle tests run when leaf_period iterations have passed since the last ones or
                                             // 1/leaf_den of the traversing lanes wait for one (pt_kernel.hip "leaf phases"); period 1 = always
@@ -88,16 +85,14 @@ constexpr int kWavesPerBlock = 4;
 #define MIPT_TRI_POS_STRIDE 64
 #endif
 constexpr uint32_t kTriPosStride = MIPT_TRI_POS_STRIDE;   // bytes per record of the intersection stream: 48 packed, 64 = never straddles a 128-B line
-constexpr int kTopPairs = 127;              // tree-top pairs staged in LDS (7 levels, 8 KB per block) when MIPT_LDS_TOP is on
-constexpr uint32_t kTopFlag = 0x40000000u;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
 constexpr uint32_t kMaxTris = 1u << 25;     // stack-entry encoding: 25-bit triangle index
 constexpr uint32_t kMaxPairs = 1u << 24;    // 24-bit pair index in the child-ref form
 
 // Launchers (stream-ordered; no allocation, no synchronisation inside).
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool lds_top, int shading,
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int shading,
                         int grid_blocks, hipStream_t stream);
-int trace_blocks_per_cu(bool count, bool cull, bool lds_top, int shading);     // occupancy query
+int trace_blocks_per_cu(bool count, bool cull, int shading);     // occupancy query
 hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t height,
                                uint32_t tile_world, float *hdr, hipStream_t stream);
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,

@@ -322,18 +322,13 @@ __device__ __forceinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 
 #ifndef MIPT_MIN_WAVES_SHADING1
 #define MIPT_MIN_WAVES_SHADING1 4      // wgpu-shader shading, fully inlined: 128 VGPRs + 56 B scratch (146 without the bound = 3 waves)
 #endif
-template <bool COUNT, bool CULL, bool LDS_TOP, int SHADING>
+template <bool COUNT, bool CULL, int SHADING>
 __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? MIPT_MIN_WAVES_PER_SIMD : MIPT_MIN_WAVES_UNCULLED) : MIPT_MIN_WAVES_SHADING1) void pt_trace_kernel(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];   // row kStackLds: scratch target of the branch-free push
-    __shared__ float4 s_top[LDS_TOP ? kTopPairs * 4 : 1];
     __shared__ double s_logtab[32];                                    // __logf_data.tab (16 x {invc, logc}) for gl_log10f
     __shared__ __attribute__((aligned(16))) float s_draw[kWavesPerBlock][64 * 6];                   // scatter draws of a service pass: 3 x {u_theta, u_rho} per hit lane, compacted
     if (threadIdx.x < 32u) s_logtab[threadIdx.x] = gl_d(glibc_logf_tab, (int)threadIdx.x);
     __syncthreads();
-    if (LDS_TOP) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kTopPairs * 4u; i += kBlockThreads) s_top[i] = sc.top[i];
-        __syncthreads();
-    }
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;
@@ -541,7 +536,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
                 best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;
                 rd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 dir_safe = ray_safe(o, d, sc.tiny_axes);
-                sp = 0; pair = LDS_TOP ? kTopFlag : 0u;
+                sp = 0; pair = 0u;
                 tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;   // root leaf (root_n > 0) or inner (empty range)
                 if (COUNT) c_rays++;
             }
@@ -581,13 +576,8 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
             // top of the stack, read now so that its LDS latency hides under the global loads: a step that pops never pushes
             const uint32_t top_e = stk[(sp - 1u) & (uint32_t)(kStackLds - 1)][lane];
             float4 r0, r1, r2, r3;
-            if (LDS_TOP && !leaf && (pair & kTopFlag)) {                 // tree top: 64 B from LDS
-                const float4 *q = s_top + (pair & 0xffffu) * 4u;
-                r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3];
-            } else {
-                r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
-                r3 = ldg4(geom, voff + 48u);                             // tri_pos is padded by one float4
-            }
+            r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
+            r3 = ldg4(geom, voff + 48u);                                 // tri_pos is padded by one float4
             // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
             // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
             asm volatile("" ::: "memory");
@@ -763,44 +753,34 @@ hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, flo
     return hipGetLastError();
 }
 
-template <bool COUNT, bool CULL, bool TOP, int SHADING>
+template <bool COUNT, bool CULL, int SHADING>
 static hipError_t launch_t(const DevScene &sc, const DevParams &pr, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL, TOP, SHADING>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
+    hipLaunchKernelGGL((pt_trace_kernel<COUNT, CULL, SHADING>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
     return hipGetLastError();
 }
-template <bool COUNT, bool CULL, bool TOP, int SHADING>
+template <bool COUNT, bool CULL, int SHADING>
 static int occ_t() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, TOP, SHADING>, kBlockThreads, 0) != hipSuccess) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, SHADING>, kBlockThreads, 0) != hipSuccess) n = 1;
     return n;
 }
-// instantiations: CPU-backend shading x {count, cull} (x lds_top in a TUNING build); wgpu-shader shading x {count, cull}
-#ifdef MIPT_TUNING
-#define MIPT_DISPATCH_TOP(FN, ...)                                                                                      \
-        if (top) {                                                                                                      \
-            if (count) return cull ? FN<true, true, true, 0>(__VA_ARGS__) : FN<true, false, true, 0>(__VA_ARGS__);      \
-            return cull ? FN<false, true, true, 0>(__VA_ARGS__) : FN<false, false, true, 0>(__VA_ARGS__);               \
-        }
-#else
-#define MIPT_DISPATCH_TOP(FN, ...) (void)top;
-#endif
+// instantiations: {CPU-backend shading, wgpu-shader shading} x {count, cull}
 #define MIPT_DISPATCH(FN, ...)                                                                                          \
     do {                                                                                                                \
         if (shading == 1) {                                                                                             \
-            if (count) return cull ? FN<true, true, false, 1>(__VA_ARGS__) : FN<true, false, false, 1>(__VA_ARGS__);    \
-            return cull ? FN<false, true, false, 1>(__VA_ARGS__) : FN<false, false, false, 1>(__VA_ARGS__);             \
+            if (count) return cull ? FN<true, true, 1>(__VA_ARGS__) : FN<true, false, 1>(__VA_ARGS__);                  \
+            return cull ? FN<false, true, 1>(__VA_ARGS__) : FN<false, false, 1>(__VA_ARGS__);                           \
         }                                                                                                               \
-        MIPT_DISPATCH_TOP(FN, __VA_ARGS__)                                                                              \
-        if (count) return cull ? FN<true, true, false, 0>(__VA_ARGS__) : FN<true, false, false, 0>(__VA_ARGS__);        \
-        return cull ? FN<false, true, false, 0>(__VA_ARGS__) : FN<false, false, false, 0>(__VA_ARGS__);                 \
+        if (count) return cull ? FN<true, true, 0>(__VA_ARGS__) : FN<true, false, 0>(__VA_ARGS__);                      \
+        return cull ? FN<false, true, 0>(__VA_ARGS__) : FN<false, false, 0>(__VA_ARGS__);                               \
     } while (0)
 
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, bool top, int shading, int grid, hipStream_t stream) {
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int shading, int grid, hipStream_t stream) {
     MIPT_DISPATCH(launch_t, sc, pr, grid, stream);
 }
-static int occ_dispatch(bool count, bool cull, bool top, int shading) { MIPT_DISPATCH(occ_t); }
-int trace_blocks_per_cu(bool count, bool cull, bool top, int shading) {
-    int n = occ_dispatch(count, cull, top, shading);
+static int occ_dispatch(bool count, bool cull, int shading) { MIPT_DISPATCH(occ_t); }
+int trace_blocks_per_cu(bool count, bool cull, int shading) {
+    int n = occ_dispatch(count, cull, shading);
     if (n < 1) n = 1;
     if (n > 8) n = 8;
     return n;

@@ -459,19 +459,6 @@ def test_progressive_accumulation_and_postprocess(rrt, orc, tmp_path):
     assert lib.mipt_render_device(hnd, L.ptr(sc.camera.uniform), C.byref(o), C.c_void_p(acc.data_ptr()), None, stream, None) == L.ERR_INVALID_ARG
 
 
-def test_lds_tree_top_variant_is_bit_exact(rrt, orc, monkeypatch):
-    """The opt-in kernel variant that serves the first 127 BVH pairs from LDS (MIPT_LDS_TOP=1; measured slower)
-    must produce the same pixels and counters."""
-    monkeypatch.setenv("MIPT_LDS_TOP", "1")
-    sc = _scene(rrt, "atrium", n_target=60000, tex_size=64)
-    for trav in (0, 1):
-        hdr, rgba, st = _render(rrt, sc, 128, 72, 2, 16, traversal=trav)
-        ref, ref_rgba, rst = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, 128, 72, 2, 16,
-                                        cull=trav, cull_margin=0.0078125)
-        assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgba, ref_rgba)
-        assert st["inner_steps"] == rst["inner_steps"] and st["tri_tests"] == rst["tri_tests"]
-
-
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_random_scenes_match_oracle(rrt, orc, seed):
     """Random triangle soups with degenerate / axis-aligned / coincident geometry, random emissive + textured materials and
