@@ -275,7 +275,9 @@ static inline float intersect_node(const Ray *ray, const OrcNode *node, int cull
     return ORC_MISS;
 }
 
-typedef struct { OrcStats s; uint32_t stack_cap; int cull; float cull_scale; int libm; float *rec; uint32_t rec_cap, rec_n; uint32_t cur_tri; } Ctx;
+typedef struct { OrcStats s; uint32_t stack_cap; int cull; float cull_scale; int libm; float *rec; uint32_t rec_cap, rec_n; uint32_t cur_tri;
+                 uint32_t *vlog; uint64_t vlog_cap, vlog_n; } Ctx;   /* vlog: record-visit trace (orc_visit_log) */
+#define VLOG(cx, word) do { if ((cx)->vlog) { if ((cx)->vlog_n < (cx)->vlog_cap) (cx)->vlog[(cx)->vlog_n] = (word); (cx)->vlog_n++; } } while (0)
 
 #define ORC_STACK_MAX 256
 static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx) { /* ray.rs:84-139 */
@@ -283,11 +285,13 @@ static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx)
     uint32_t sp = 0;
     const OrcNode *node = &sc->nodes[0];
     cx->s.rays++;
+    VLOG(cx, 0xffffffffu);
     for (;;) {
         if (node->num_tris > 0) {
             for (uint32_t i = 0; i < node->num_tris; i++) {
                 Hit th = intersect_tri(ray, &sc->tris[node->first_tri_or_child + i]);
                 cx->s.tri_tests++;
+                VLOG(cx, 0x80000000u | (node->first_tri_or_child + i));
                 if (th.has_hit && th.distance < hit->distance) { *hit = th; cx->cur_tri = node->first_tri_or_child + i; }
             }
             if (sp == 0) break;
@@ -296,6 +300,7 @@ static void traverse_bvh(const Ray *ray, const SceneView *sc, Hit *hit, Ctx *cx)
         }
         uint32_t c1 = node->first_tri_or_child, c2 = c1 + 1;
         cx->s.inner_steps++;
+        VLOG(cx, (c1 - 1u) / 2u);
         const float max_d = hit->distance * cx->cull_scale;
         float dist_1 = intersect_node(ray, &sc->nodes[c1], cx->cull, max_d);
         float dist_2 = intersect_node(ray, &sc->nodes[c2], cx->cull, max_d);
@@ -339,6 +344,7 @@ static v3 trace(Ray *ray, uint32_t max_bounces, const SceneView *sc, uint32_t *r
         }
         if (hit.has_hit) {
             cx->s.hits++;
+            VLOG(cx, 0xc0000000u | cx->cur_tri);
             const OrcMaterial *m = &sc->materials[hit.material_id];   /* ray.rs:153-154 */
             /* ray.rs:155-160: `ior` is computed and never used on the CPU path (T8) */
             if (m->base_color_tex_id != UINT32_MAX) {                  /* ray.rs:162-169 */
@@ -695,6 +701,32 @@ uint32_t orc_debug_pixel(const OrcTriangle *tris, uint32_t n_tris, const OrcNode
     if (out_rgb) { out_rgb[0] = hdr[3 * pixel_index]; out_rgb[1] = hdr[3 * pixel_index + 1]; out_rgb[2] = hdr[3 * pixel_index + 2]; }
     free(hdr);
     return cx.rec_n;
+}
+
+/* Analysis aid for the device record layout (tests/tools/layout_model.py): renders pixels pix_begin, pix_begin + stride, ... (n_pixels
+ * of them, all samples and bounces, shading mode 0) on one thread and logs which BVH records every ray touches, in order:
+ * 0xffffffff = a new ray; k < 2^30 = inner step on child pair k (nodes 2k+1, 2k+2); 0x80000000|i = triangle test i;
+ * 0xc0000000|i = attribute fetch of the winning triangle.  Returns the number of words the full log needs (may exceed cap). */
+uint64_t orc_visit_log(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+                       const OrcMaterial *materials, uint32_t n_materials, const OrcTexture *textures, uint32_t n_textures,
+                       const OrcCamera *camera, const OrcOptions *opt, uint64_t pix_begin, uint64_t pix_stride, uint64_t n_pixels,
+                       uint32_t *log, uint64_t cap) {
+    Job job; memset(&job, 0, sizeof job);
+    job.sc.tris = tris; job.sc.n_tris = n_tris; job.sc.nodes = nodes; job.sc.n_nodes = n_nodes;
+    job.sc.materials = materials; job.sc.n_materials = n_materials;
+    job.sc.textures = textures; job.sc.n_textures = n_textures;
+    job.cam = camera; job.opt = *opt;
+    Ctx cx; memset(&cx, 0, sizeof cx);
+    cx.stack_cap = opt->stack_cap ? opt->stack_cap : 64;
+    cx.cull = (int)opt->cull; cx.libm = (int)opt->libm; cx.cull_scale = 1.0f + opt->cull_margin;
+    cx.vlog = log; cx.vlog_cap = cap;
+    const uint64_t n_all = (uint64_t)opt->width * opt->height;
+    for (uint64_t i = 0; i < n_pixels; i++) {
+        const uint64_t index = pix_begin + i * pix_stride;
+        if (index >= n_all) break;
+        render_pixel(&job, index, &cx);
+    }
+    return cx.vlog_n;
 }
 
 int orc_render(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,

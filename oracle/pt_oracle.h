@@ -119,6 +119,11 @@ int orc_render(const OrcTriangle *tris, uint32_t n_tris,
                const OrcCamera *camera, const OrcOptions *opt,
                float *hdr, uint8_t *rgba8, OrcStats *stats);
 
+/* record-visit trace for layout analysis (tests/tools/layout_model.py); see pt_oracle.c */
+uint64_t orc_visit_log(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
+                       const OrcMaterial *materials, uint32_t n_materials, const OrcTexture *textures, uint32_t n_textures,
+                       const OrcCamera *camera, const OrcOptions *opt, uint64_t pix_begin, uint64_t pix_stride, uint64_t n_pixels,
+                       uint32_t *log, uint64_t cap);
 uint32_t orc_debug_pixel(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
                          const OrcMaterial *materials, uint32_t n_materials,
                          const OrcTexture *textures, uint32_t n_textures,

@@ -267,10 +267,26 @@ extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nod
 }
 
 // ---- order of the device's 64-B pair records (pair k = {nodes[2k+1], nodes[2k+2]}; mipt_api.cpp builds the records) ----
-// Breadth-first, every level starting on a 128-B line (an even record index), and within a level first the couples -- the two
-// child pairs of a node with two inner children, adjacent: one line -- then the child pairs of nodes with one inner child.
+// The memory side moves whole 128-B lines and a traversal step gathers ONE 64-B record, so what matters is which record shares a
+// record's line.  Two zones:
+//   * the top kPairLayoutTop levels, which every ray walks through and which stay resident in L1 / L2: breadth-first, level after
+//     level, every level starting on a line boundary -- one dense run of lines;
+//   * below them, where a line is cold whenever a ray reaches it: a pair shares its line with the child pair of its LARGER inner
+//     child (half area: SAH's own proxy for "the child the ray enters").  The step after a cold pair is then a hit more often than
+//     not.  A pair that was taken into its parent's line leaves its own children to head new lines; pairs with two leaf children
+//     that nobody took are packed two by two at the end, in level order (siblings are neighbours there).
+// Measured on config M (tools/ab_pmc.sh, profiles/r3_layout_ab.csv): 12.8 -> 10.0 line fills per ray against the round-2 order
+// (breadth-first with the two child pairs of a node in one line, which only moved hits from L2 to L1); the order was picked with
+// the replay model of tests/tools/layout_model.py (predicted 12.2 -> 10.0).  Topology, visit order and results are untouched.
 // order_out[j] = reference pair index of record j, or 0xffffffff for a pad record; *n_records_out = number of records.
 // Internal to the library (declared where it is used); exported for tests/test_host_layout.py.
+#ifndef MIPT_PAIR_LAYOUT
+#define MIPT_PAIR_LAYOUT 3          // 1 = the round-2 order (breadth-first couples) for A/B builds
+#endif
+#ifndef MIPT_PAIR_LAYOUT_TOP
+#define MIPT_PAIR_LAYOUT_TOP 12     // 8 ... 14 measure the same (2.005 - 2.03 G fills per frame); 16: 2.20, 18: 2.31, 0: 2.23
+#endif
+extern "C" uint32_t mipt_internal_pair_order_top(void) { return MIPT_PAIR_LAYOUT == 3 ? (uint32_t)MIPT_PAIR_LAYOUT_TOP : 0xffffffffu; }
 extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out) {
     if (!nodes || !order_out || !n_records_out || (n_nodes & 1u) == 0u) return MIPT_ERR_INVALID_ARG;
     try {
@@ -285,6 +301,49 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         };
         std::vector<uint32_t> level, couples, singles;
         if (n_pairs > 0) level.push_back(0u);
+#if MIPT_PAIR_LAYOUT == 3
+        std::vector<uint8_t> taken(n_pairs, 0);
+        std::vector<uint32_t> lone;
+        auto half_area = [&](uint32_t node) -> double {
+            const MiptNode &n = nodes[node];
+            const double ex = (double)n.bounds_max.x - n.bounds_min.x, ey = (double)n.bounds_max.y - n.bounds_min.y, ez = (double)n.bounds_max.z - n.bounds_min.z;
+            return ex * ey + ey * ez + ez * ex;
+        };
+        uint32_t depth = 0;
+        while (!level.empty()) {
+            if (order.size() + 2 * level.size() + 2 > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;
+            couples.clear(); singles.clear();
+            if (depth < (uint32_t)MIPT_PAIR_LAYOUT_TOP) {
+                if (order.size() & 1u) order.push_back(0xffffffffu);
+                for (uint32_t k : level) order.push_back(k);
+            } else {
+                for (uint32_t k : level) {
+                    if (taken[k]) continue;
+                    uint32_t ca = 0, cb = 0;
+                    const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
+                    if (!ha && !hb) { lone.push_back(k); continue; }
+                    uint32_t pick = ha ? ca : cb;
+                    if (ha && hb && half_area(2 * k + 2) > half_area(2 * k + 1)) pick = cb;
+                    if (order.size() & 1u) order.push_back(0xffffffffu);
+                    order.push_back(k); order.push_back(pick);
+                    taken[pick] = 1;
+                }
+            }
+            for (uint32_t k : level) {
+                uint32_t ca = 0, cb = 0;
+                const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
+                if (ha && hb) { couples.push_back(ca); couples.push_back(cb); }
+                else if (ha) singles.push_back(ca);
+                else if (hb) singles.push_back(cb);
+            }
+            level = couples;
+            level.insert(level.end(), singles.begin(), singles.end());
+            depth++;
+        }
+        if (order.size() & 1u) order.push_back(0xffffffffu);
+        if (order.size() + lone.size() > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;
+        for (uint32_t k : lone) order.push_back(k);      // level order: sibling pairs that are both free are neighbours (and mostly line mates)
+#else
         while (!level.empty()) {
             if (order.size() & 1u) order.push_back(0xffffffffu);            // every level starts on a line boundary
             if (order.size() + level.size() > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;   // also bounds a malformed (shared-child) input
@@ -300,6 +359,7 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
             level = couples;
             level.insert(level.end(), singles.begin(), singles.end());
         }
+#endif
         if (order.size() > cap) return MIPT_ERR_SCENE_LIMIT;
         for (size_t j = 0; j < order.size(); j++) order_out[j] = order[j];
         *n_records_out = (uint32_t)order.size();

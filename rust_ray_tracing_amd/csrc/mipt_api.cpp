@@ -141,7 +141,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     // ---- validate and re-base the BVH: pair[k] = {nodes[2k+1], nodes[2k+2]} ----
     uint32_t max_leaf = 0;
     uint32_t tiny_axes = 0;
-    std::vector<uint8_t> pair_seen(n_pairs, 0);
+    std::vector<uint8_t> pair_seen(n_pairs, 0), tri_seen(desc->n_tris, 0);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const MiptNode &n = desc->nodes[i];
         {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused); axes on which some
@@ -159,6 +159,12 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             if ((uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris)
                 return fail(MIPT_ERR_BVH, "leaf node %u covers triangles [%u, %u+%u) beyond n_tris=%u", i, n.first_tri_or_child, n.first_tri_or_child, n.num_tris, desc->n_tris);
             if (n.num_tris > max_leaf) max_leaf = n.num_tris;
+            // leaves partition the triangle array (bvh.rs:99-115 splits a node's range in place); the device stream re-packs
+            // leaf by leaf, so a triangle in two leaves cannot be represented
+            for (uint32_t t = n.first_tri_or_child; t < n.first_tri_or_child + n.num_tris; t++) {
+                if (tri_seen[t]) return fail(MIPT_ERR_BVH, "triangle %u belongs to more than one leaf (node %u is the second)", t, i);
+                tri_seen[t] = 1;
+            }
         } else {
             const uint32_t c = n.first_tri_or_child;
             if ((c & 1u) == 0u || (uint64_t)c + 1u >= desc->n_nodes || c <= i)
@@ -171,11 +177,59 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     }
     for (uint32_t k = 0; k < n_pairs; k++)
         if (!pair_seen[k]) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * k + 1, 2 * k + 2);
+    // ---- slots of the intersection stream: where triangle i's 64-B record sits (two records per 128-B line) ----
+    // The memory side moves whole lines, a leaf holds 1 or 2 triangles almost always (binned SAH: avg 1.32) and the two leaves of a
+    // pair are usually tested one after the other.  So the records are re-packed -- the stream's order is free, a leaf only needs
+    // its own triangles consecutive: first every "double" gets a line to itself (a 2-triangle leaf, or the two 1-triangle
+    // leaves of one pair, whose triangles are neighbours in the reference order: bvh.rs:99-115 partitions a node's range in
+    // place), then all remaining triangles follow in the reference order.  The record carries the triangle's reference index
+    // (word 9), which is what a hit reports.  Model (tests/tools/layout_model.py): 2.8 -> 2.0 line fills per ray for triangle tests.
+    std::vector<uint32_t> slot_of_tri(desc->n_tris);
+    {
+        uint32_t next = 0;
+#ifndef MIPT_TRI_LAYOUT
+#define MIPT_TRI_LAYOUT 1
+#endif
+#if MIPT_TRI_LAYOUT == 1
+        std::vector<uint8_t> placed(desc->n_tris, 0);
+        auto leaf1 = [&](const MiptNode &n) { return n.num_tris == 1u; };
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            const MiptNode &l = desc->nodes[2 * k + 1], &r = desc->nodes[2 * k + 2];
+            if (leaf1(l) && leaf1(r) && r.first_tri_or_child == l.first_tri_or_child + 1u) {
+                slot_of_tri[l.first_tri_or_child] = next++; slot_of_tri[r.first_tri_or_child] = next++;
+                placed[l.first_tri_or_child] = placed[r.first_tri_or_child] = 1;
+                continue;
+            }
+            for (const MiptNode *n : {&l, &r})
+                if (n->num_tris == 2u) {
+                    slot_of_tri[n->first_tri_or_child] = next++; slot_of_tri[n->first_tri_or_child + 1u] = next++;
+                    placed[n->first_tri_or_child] = placed[n->first_tri_or_child + 1u] = 1;
+                }
+        }
+        for (uint32_t i = 0; i < desc->n_tris; i++)
+            if (!placed[i]) slot_of_tri[i] = next++;
+#elif MIPT_TRI_LAYOUT == 2
+        // reference order kept (neighbouring leaves stay neighbours in memory), one pad slot wherever a double would straddle a line
+        std::vector<uint8_t> starts_double(desc->n_tris, 0);
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            const MiptNode &l = desc->nodes[2 * k + 1], &r = desc->nodes[2 * k + 2];
+            if (l.num_tris == 1u && r.num_tris == 1u && r.first_tri_or_child == l.first_tri_or_child + 1u) starts_double[l.first_tri_or_child] = 1;
+            if (l.num_tris == 2u) starts_double[l.first_tri_or_child] = 1;
+            if (r.num_tris == 2u) starts_double[r.first_tri_or_child] = 1;
+        }
+        for (uint32_t i = 0; i < desc->n_tris; i++) {
+            if (starts_double[i] && (next & 1u)) next++;
+            slot_of_tri[i] = next++;
+        }
+#else
+        for (uint32_t i = 0; i < desc->n_tris; i++) slot_of_tri[i] = next++;
+#endif
+    }
     std::vector<float4> pairs((size_t)n_pairs * 4);
     for (uint32_t k = 0; k < n_pairs; k++) {
         for (uint32_t w = 0; w < 2; w++) {
             const MiptNode &n = desc->nodes[2 * k + 1 + w];
-            const uint32_t a = n.num_tris > 0 ? n.first_tri_or_child : (n.first_tri_or_child - 1u) / 2u;
+            const uint32_t a = n.num_tris > 0 ? slot_of_tri[n.first_tri_or_child] : (n.first_tri_or_child - 1u) / 2u;
             float4 lo, hi;
             lo.x = n.bounds_min.x; lo.y = n.bounds_min.y; lo.z = n.bounds_min.z; memcpy(&lo.w, &a, 4);
             hi.x = n.bounds_max.x; hi.y = n.bounds_max.y; hi.z = n.bounds_max.z; memcpy(&hi.w, &n.num_tris, 4);
@@ -183,13 +237,9 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             pairs[(size_t)k * 4 + w * 2 + 1] = hi;
         }
     }
-    // ---- order of the pair records in HBM: breadth-first, sibling pairs in one 128-B line ----
-    // The memory side moves whole 128-B lines (profiles/r2_fetch_calibration.csv) and a step uses one 64-B record, so a record's
-    // line mate should be one the ray needs soon.  The reference's array is depth-first (left child's pair = next record: a line
-    // mate half the time, the right child's pair far away).  Here a node's two child pairs sit in ONE line and levels follow
-    // each other: a miss on either child brings the sibling that the ray usually visits next (it is on the stack), and the top of
-    // the tree -- what every ray walks through -- is one dense run of lines.  Topology, visit order and results are untouched;
-    // only `a` of the inner children is renumbered.  Config M: 78.2-78.6 -> 75.6-76.1 ms (-DMIPT_PAIR_LAYOUT=0 restores the old order).
+    // ---- order of the pair records in HBM (mipt_internal_pair_order, bvh_build.cpp): the tree top breadth-first, below it every
+    // pair in one 128-B line with the child pair of its larger inner child.  Topology, visit order and results are untouched; only
+    // `a` of the inner children is renumbered.  (-DMIPT_PAIR_LAYOUT=0 keeps the reference's depth-first order, =1 the round-2 order.)
     std::vector<uint32_t> new_of(n_pairs);                                  // reference pair index -> record index in HBM
     for (uint32_t k = 0; k < n_pairs; k++) new_of[k] = k;
 #if !defined(MIPT_PAIR_LAYOUT) || MIPT_PAIR_LAYOUT != 0
@@ -221,9 +271,13 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         pairs.swap(re);
     }
 #endif
+    if ((pairs.size() / 4) & 1u) pairs.insert(pairs.end(), 4, make_float4(0, 0, 0, 0));   // the triangle stream behind it starts on a 128-B line
     const uint32_t n_pair_records = (uint32_t)(pairs.size() / 4);
     // ---- triangles: 64-B-strided intersection stream + 64-B shading stream ----
-    std::vector<float4> tri_pos((size_t)desc->n_tris * mipt::kTriPosStride / 16 + 1);   // +1: the kernel's unconditional 4th float4 load
+    uint32_t n_slots = 0;
+    for (uint32_t i = 0; i < desc->n_tris; i++) if (slot_of_tri[i] + 1u > n_slots) n_slots = slot_of_tri[i] + 1u;
+    if (n_slots > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, "%u triangle slots exceed the 2^25 device-format limit", n_slots);
+    std::vector<float4> tri_pos((size_t)n_slots * mipt::kTriPosStride / 16 + 1, make_float4(0, 0, 0, 0));   // +1: the kernel's unconditional 4th float4 load
     std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
     for (uint32_t i = 0; i < desc->n_tris; i++) {
         const MiptTriangle &t = desc->tris[i];
@@ -234,10 +288,12 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         // the same value the reference recomputes per test (-ffp-contract=off; no fusing possible here).
         const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
         const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
-        const size_t q = (size_t)i * (mipt::kTriPosStride / 16);
+        const size_t q = (size_t)slot_of_tri[i] * (mipt::kTriPosStride / 16);
+        float idf;
+        memcpy(&idf, &i, 4);
         tri_pos[q + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
         tri_pos[q + 1] = make_float4(e1y, e1z, e2x, e2y);
-        tri_pos[q + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+        tri_pos[q + 2] = make_float4(e2z, idf, 0.0f, 0.0f);
         const MiptVec3 n0 = t.vertices[0].normal, n1 = t.vertices[1].normal, n2 = t.vertices[2].normal;
         float mid;
         memcpy(&mid, &t.material_id, 4);
@@ -246,7 +302,6 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         tri_attr[(size_t)i * 4 + 2] = make_float4(n2.z, t.vertices[0].tex_coord_x, t.vertices[0].tex_coord_y, t.vertices[1].tex_coord_x);
         tri_attr[(size_t)i * 4 + 3] = make_float4(t.vertices[1].tex_coord_y, t.vertices[2].tex_coord_x, t.vertices[2].tex_coord_y, mid);
     }
-    tri_pos[(size_t)desc->n_tris * (mipt::kTriPosStride / 16)] = make_float4(0, 0, 0, 0);
     // ---- materials / textures ----
     struct TexDesc { uint32_t offset, width, height; };
     std::vector<TexDesc> texs(desc->n_textures);
@@ -339,7 +394,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     s->dev.texels = (const uint32_t *)s->d_texels;
     s->dev.n_pairs = n_pair_records; s->dev.n_tris = desc->n_tris; s->dev.n_mats = desc->n_materials; s->dev.n_texs = desc->n_textures;
     // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0
-    s->dev.root_a = desc->nodes[0].num_tris > 0 ? desc->nodes[0].first_tri_or_child : 0u;
+    s->dev.root_a = desc->nodes[0].num_tris > 0 ? slot_of_tri[desc->nodes[0].first_tri_or_child] : 0u;
     s->dev.root_n = desc->nodes[0].num_tris;
     *out = s;
     return MIPT_OK;

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
                 const bool has_hit = (t > 0.0f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
                 if (has_hit && t < best_t) {                                         // ray.rs:96 (strict <)
                     best_t = t; best_u = u; best_v = v;
-                    best_tri = tri_cur | ((det > 0.0f) ? kFrontBit : 0u);            // ray.rs:39
+                    best_tri = __float_as_uint(r2.y) | ((det > 0.0f) ? kFrontBit : 0u);   // the record carries its triangle's index in the reference order; ray.rs:39
                 }
                 if (COUNT) c_tris++;
                 tri_cur += 1;
