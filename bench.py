@@ -313,16 +313,19 @@ def main():
         """Counting build, outside the timed region (deterministic: same counts as the timed launches).
         Returns (whole-job totals, the counts of rank 0's / device 0's own launch)."""
         if single:
-            tot_st = render_node(mode, extra_flags=L.FLAG_COUNT)
+            tot_st = render_node(mode, extra_flags=L.FLAG_COUNT | L.FLAG_TOUCHED)
             d0 = L.MiptStats()
             L.check(lib.mipt_multi_device_stats(multi, 0, C.byref(d0)), "mipt_multi_device_stats")
-            return {k: int(tot_st[k]) for k in COUNT_KEYS}, {k: int(getattr(d0, k)) for k in COUNT_KEYS}
+            local = {k: int(getattr(d0, k)) for k in COUNT_KEYS}
+            local["touched_lines"] = list(d0.touched_lines)
+            return {k: int(tot_st[k]) for k in COUNT_KEYS}, local
         if mode == "samples" and s_count == 0:
             cst = {k: 0 for k in COUNT_KEYS}
         else:
-            cst = render(mode, extra_flags=L.FLAG_COUNT)
+            cst = render(mode, extra_flags=L.FLAG_COUNT | L.FLAG_TOUCHED)
         counts = torch.tensor([cst[k] for k in COUNT_KEYS], dtype=torch.int64, device=dev)
         local_counts = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
+        local_counts["touched_lines"] = list(cst.get("touched_lines", [0, 0]))
         if world > 1:
             all_reduce_(counts)
         return {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}, local_counts
@@ -368,6 +371,7 @@ def main():
     alg_bytes = algorithmic_bytes(local_counts, n_local_samples)
     dev_bytes = device_bytes(local_counts, local_counts["pixels"])
     achieved = alg_bytes / avg_kernel_s / 1e9
+    unique_bytes = (sum(local_counts["touched_lines"]) * 128 + 12 * local_counts["pixels"]) if sum(local_counts["touched_lines"]) else None
     traffic, prov = pmc_traffic(args.tris, w, h, spp, depth, args.traversal, mode) if world == 1 else (None, "N > 1")
     seeds = "pixel-stream seeds (cpu.rs:28-29)" if mode == "tiles" else "per-sample seeds (rt_compute.wgsl:102)"
     how = ("one process, mipt_multi_create (ncclCommInitAll) + one mipt_render_multi_device call per frame" if single
@@ -401,6 +405,11 @@ def main():
                                      f"null: {prov}",
                      "traffic_provenance": prov if traffic else None,
                      "memside_frac_measured": round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                     # compulsory traffic: distinct 128-B lines of the BVH / triangle / attribute streams this launch reads (device bitmap
+                     # in the counting launch, MIPT_FLAG_TOUCHED) x 128 B + the framebuffer; traffic / this = how often a line is re-fetched
+                     "unique_line_bytes": unique_bytes,
+                     "unique_lines": {"bvh_pairs_and_triangle_stream": local_counts["touched_lines"][0], "triangle_attributes": local_counts["touched_lines"][1]},
+                     "refetch_factor": round(traffic / unique_bytes, 1) if traffic and unique_bytes else None,
                      "kernel": "pt_trace_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3), "kernel_source_sha": kernel_source_sha(),
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": round(alg_bytes / max(local_counts["rays"], 1), 1),
                      "device_bytes_per_launch": dev_bytes, "device_GBs": round(dev_bytes / avg_kernel_s / 1e9, 1),

@@ -102,8 +102,11 @@ enum MiptFlags {
     MIPT_FLAG_COUNT  = 1u << 0,   /* counting build: fill rays / inner_steps / tri_tests / ... in MiptStats */
     MIPT_FLAG_PACKED = 1u << 1,   /* tile-sharded output is rank-packed (tile-major) instead of full-frame */
     MIPT_FLAG_SUM    = 1u << 2,   /* hdr = sum over samples (no division): sample-sharded accumulation */
-    MIPT_FLAG_ACCUM  = 1u << 3    /* with SUM, device buffers only: hdr += this call's samples (progressive rendering,
+    MIPT_FLAG_ACCUM  = 1u << 3,   /* with SUM, device buffers only: hdr += this call's samples (progressive rendering,
                                    * the resumable form of the per-sample loop at gpu.rs:17-77) */
+    MIPT_FLAG_TOUCHED = 1u << 4   /* with COUNT: also mark every 128-byte line of the BVH / triangle streams the launch reads in a
+                                   * device bitmap and report the number of distinct lines (MiptStats.touched_lines): the
+                                   * compulsory memory traffic of the frame.  Diagnostic: slows the counting launch down */
 };
 
 typedef struct {
@@ -137,6 +140,9 @@ typedef struct {
      * wave-cycles inside service passes; wave-cycles alive; wave-cycles waiting for the traversal loads (only in a
      * -DMIPT_DIAG_STAMPS=1 build); wave-cycles between a wave first finding the queue empty and its exit (tail) */
     uint64_t diag[11];
+    /* [COUNT | TOUCHED] distinct 128-byte lines read: [0] of the BVH pair records + triangle intersection stream (one
+     * allocation), [1] of the triangle attribute stream.  x 128 = the bytes a launch must move at least once. */
+    uint64_t touched_lines[2];
 } MiptStats;
 
 enum MiptStatus {

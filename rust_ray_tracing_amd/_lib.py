@@ -31,7 +31,7 @@ NO_TEXTURE = 0xFFFFFFFF
 SEED_PIXEL_STREAM, SEED_PER_SAMPLE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
 SHADING_CPU, SHADING_WGPU = 0, 1
-FLAG_COUNT, FLAG_PACKED, FLAG_SUM, FLAG_ACCUM = 1, 2, 4, 8
+FLAG_COUNT, FLAG_PACKED, FLAG_SUM, FLAG_ACCUM, FLAG_TOUCHED = 1, 2, 4, 8, 16
 CULL_MARGIN_SAFE = 0.0078125  # MIPT_CULL_MARGIN_SAFE
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_SCENE_LIMIT, ERR_BVH, ERR_IO, ERR_STACK, ERR_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
@@ -60,11 +60,12 @@ class MiptStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("rays", C.c_uint64), ("inner_steps", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("hits", C.c_uint64), ("texel_fetches", C.c_uint64),
                 ("stack_overflows", C.c_uint64), ("tex_clamped", C.c_uint64), ("max_stack", C.c_uint64),
-                ("pixels", C.c_uint64), ("diag", C.c_uint64 * 11)]
+                ("pixels", C.c_uint64), ("diag", C.c_uint64 * 11), ("touched_lines", C.c_uint64 * 2)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "diag"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("diag", "touched_lines")}
         d["diag"] = list(self.diag)
+        d["touched_lines"] = list(self.touched_lines)
         return d
 
 

@@ -368,3 +368,63 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         return MIPT_ERR_INVALID_ARG;
     }
 }
+
+
+// ---- slots of the device's intersection stream: slot_out[i] = index of triangle i's 64-B record (two records per 128-B line) ----
+// The memory side moves whole lines, a leaf of the binned-SAH tree holds 1 or 2 triangles almost always (avg 1.32 on the 10 M-triangle
+// scene) and the two leaves of a pair are usually tested one after the other.  The stream's order is free -- a leaf only needs its own
+// triangles consecutive -- so: first every "double" gets a line to itself (a 2-triangle leaf, or the two 1-triangle leaves of one
+// pair, whose triangles are neighbours in the reference order: bvh.rs:99-115 partitions a node's range in place), then all remaining
+// triangles follow in the reference order.  The record carries the triangle's reference index, which is what a hit reports.
+// Measured with the parent+child pair lines: 10.55 -> 10.04 line fills per ray (profiles/r3_layout_ab.csv).
+// The caller has validated the nodes (leaves partition [0, n_tris)).  Exported for tests/test_host_layout.py.
+#ifndef MIPT_TRI_LAYOUT
+#define MIPT_TRI_LAYOUT 1           // 0 = reference order, 2 = reference order + a pad slot wherever a double would straddle a line (A/B builds)
+#endif
+extern "C" int mipt_internal_tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out) {
+    if (!nodes || !slot_out || !n_slots_out || (n_nodes & 1u) == 0u) return MIPT_ERR_INVALID_ARG;
+    try {
+        const uint32_t n_pairs = (n_nodes - 1u) / 2u;
+        uint32_t next = 0;
+        auto in_range = [&](const MiptNode &n) { return n.num_tris == 0u || (uint64_t)n.first_tri_or_child + n.num_tris <= n_tris; };
+#if MIPT_TRI_LAYOUT == 1
+        std::vector<uint8_t> placed(n_tris, 0);
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            const MiptNode &l = nodes[2 * k + 1], &r = nodes[2 * k + 2];
+            if (!in_range(l) || !in_range(r)) return MIPT_ERR_BVH;
+            if (l.num_tris == 1u && r.num_tris == 1u && r.first_tri_or_child == l.first_tri_or_child + 1u) {
+                slot_out[l.first_tri_or_child] = next++; slot_out[r.first_tri_or_child] = next++;
+                placed[l.first_tri_or_child] = placed[r.first_tri_or_child] = 1;
+                continue;
+            }
+            for (const MiptNode *n : {&l, &r})
+                if (n->num_tris == 2u) {
+                    slot_out[n->first_tri_or_child] = next++; slot_out[n->first_tri_or_child + 1u] = next++;
+                    placed[n->first_tri_or_child] = placed[n->first_tri_or_child + 1u] = 1;
+                }
+        }
+        for (uint32_t i = 0; i < n_tris; i++)
+            if (!placed[i]) slot_out[i] = next++;
+#elif MIPT_TRI_LAYOUT == 2
+        std::vector<uint8_t> starts_double(n_tris, 0);
+        for (uint32_t k = 0; k < n_pairs; k++) {
+            const MiptNode &l = nodes[2 * k + 1], &r = nodes[2 * k + 2];
+            if (!in_range(l) || !in_range(r)) return MIPT_ERR_BVH;
+            if (l.num_tris == 1u && r.num_tris == 1u && r.first_tri_or_child == l.first_tri_or_child + 1u) starts_double[l.first_tri_or_child] = 1;
+            if (l.num_tris == 2u) starts_double[l.first_tri_or_child] = 1;
+            if (r.num_tris == 2u) starts_double[r.first_tri_or_child] = 1;
+        }
+        for (uint32_t i = 0; i < n_tris; i++) {
+            if (starts_double[i] && (next & 1u)) next++;
+            slot_out[i] = next++;
+        }
+#else
+        (void)n_pairs; (void)in_range;
+        for (uint32_t i = 0; i < n_tris; i++) slot_out[i] = next++;
+#endif
+        *n_slots_out = next;
+        return MIPT_OK;
+    } catch (const std::exception &) {
+        return MIPT_ERR_INVALID_ARG;
+    }
+}

@@ -24,6 +24,7 @@ static_assert(sizeof(MiptNode) == 32 && offsetof(MiptNode, first_tri_or_child) =
 static_assert(sizeof(MiptMaterial) == 80 && offsetof(MiptMaterial, ior) == 28 && offsetof(MiptMaterial, emission) == 32 &&
                   offsetof(MiptMaterial, roughness) == 44 && offsetof(MiptMaterial, base_color_tex_id) == 56, "Material");
 static_assert(sizeof(MiptCamera) == 80 && offsetof(MiptCamera, position) == 64, "UniformCamera");
+static_assert(sizeof(MiptStats) == 8 + 22 * 8 && sizeof(MiptOptions) == 64, "ABI v3 struct sizes (tests/test_abi.py, rust_ray_tracing_amd/_lib.py)");
 static_assert(sizeof(mipt::DevMaterial) == 64 && sizeof(mipt::DevMaterialFull) == 128, "device records");
 
 namespace {
@@ -50,6 +51,7 @@ int fail(int code, const char *fmt, ...) {
 
 void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);   // bvh_build.cpp
+extern "C" int mipt_internal_tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);      // bvh_build.cpp
 
 struct MiptScene {
     int device = 0;
@@ -60,6 +62,8 @@ struct MiptScene {
     mipt::DevStats *d_stats = nullptr;
     uint32_t *d_ovf = nullptr;
     size_t ovf_waves = 0;
+    uint32_t *d_touched = nullptr;          // MIPT_FLAG_TOUCHED: line bitmap, allocated on first use
+    size_t n_tris = 0;
     float *d_hdr = nullptr;
     size_t hdr_floats = 0;
     uint8_t *d_rgba = nullptr;
@@ -75,7 +79,7 @@ void free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels,
-                    s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba};
+                    s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba, s->d_touched};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -177,54 +181,11 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     }
     for (uint32_t k = 0; k < n_pairs; k++)
         if (!pair_seen[k]) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * k + 1, 2 * k + 2);
-    // ---- slots of the intersection stream: where triangle i's 64-B record sits (two records per 128-B line) ----
-    // The memory side moves whole lines, a leaf holds 1 or 2 triangles almost always (binned SAH: avg 1.32) and the two leaves of a
-    // pair are usually tested one after the other.  So the records are re-packed -- the stream's order is free, a leaf only needs
-    // its own triangles consecutive: first every "double" gets a line to itself (a 2-triangle leaf, or the two 1-triangle
-    // leaves of one pair, whose triangles are neighbours in the reference order: bvh.rs:99-115 partitions a node's range in
-    // place), then all remaining triangles follow in the reference order.  The record carries the triangle's reference index
-    // (word 9), which is what a hit reports.  Model (tests/tools/layout_model.py): 2.8 -> 2.0 line fills per ray for triangle tests.
+    // ---- slots of the intersection stream (mipt_internal_tri_slots, bvh_build.cpp): where triangle i's 64-B record sits ----
     std::vector<uint32_t> slot_of_tri(desc->n_tris);
-    {
-        uint32_t next = 0;
-#ifndef MIPT_TRI_LAYOUT
-#define MIPT_TRI_LAYOUT 1
-#endif
-#if MIPT_TRI_LAYOUT == 1
-        std::vector<uint8_t> placed(desc->n_tris, 0);
-        auto leaf1 = [&](const MiptNode &n) { return n.num_tris == 1u; };
-        for (uint32_t k = 0; k < n_pairs; k++) {
-            const MiptNode &l = desc->nodes[2 * k + 1], &r = desc->nodes[2 * k + 2];
-            if (leaf1(l) && leaf1(r) && r.first_tri_or_child == l.first_tri_or_child + 1u) {
-                slot_of_tri[l.first_tri_or_child] = next++; slot_of_tri[r.first_tri_or_child] = next++;
-                placed[l.first_tri_or_child] = placed[r.first_tri_or_child] = 1;
-                continue;
-            }
-            for (const MiptNode *n : {&l, &r})
-                if (n->num_tris == 2u) {
-                    slot_of_tri[n->first_tri_or_child] = next++; slot_of_tri[n->first_tri_or_child + 1u] = next++;
-                    placed[n->first_tri_or_child] = placed[n->first_tri_or_child + 1u] = 1;
-                }
-        }
-        for (uint32_t i = 0; i < desc->n_tris; i++)
-            if (!placed[i]) slot_of_tri[i] = next++;
-#elif MIPT_TRI_LAYOUT == 2
-        // reference order kept (neighbouring leaves stay neighbours in memory), one pad slot wherever a double would straddle a line
-        std::vector<uint8_t> starts_double(desc->n_tris, 0);
-        for (uint32_t k = 0; k < n_pairs; k++) {
-            const MiptNode &l = desc->nodes[2 * k + 1], &r = desc->nodes[2 * k + 2];
-            if (l.num_tris == 1u && r.num_tris == 1u && r.first_tri_or_child == l.first_tri_or_child + 1u) starts_double[l.first_tri_or_child] = 1;
-            if (l.num_tris == 2u) starts_double[l.first_tri_or_child] = 1;
-            if (r.num_tris == 2u) starts_double[r.first_tri_or_child] = 1;
-        }
-        for (uint32_t i = 0; i < desc->n_tris; i++) {
-            if (starts_double[i] && (next & 1u)) next++;
-            slot_of_tri[i] = next++;
-        }
-#else
-        for (uint32_t i = 0; i < desc->n_tris; i++) slot_of_tri[i] = next++;
-#endif
-    }
+    uint32_t n_slots = 0;
+    if (mipt_internal_tri_slots(desc->nodes, desc->n_nodes, desc->n_tris, slot_of_tri.data(), &n_slots) != MIPT_OK)
+        return fail(MIPT_ERR_BVH, "triangle slots: malformed BVH");
     std::vector<float4> pairs((size_t)n_pairs * 4);
     for (uint32_t k = 0; k < n_pairs; k++) {
         for (uint32_t w = 0; w < 2; w++) {
@@ -274,8 +235,6 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     if ((pairs.size() / 4) & 1u) pairs.insert(pairs.end(), 4, make_float4(0, 0, 0, 0));   // the triangle stream behind it starts on a 128-B line
     const uint32_t n_pair_records = (uint32_t)(pairs.size() / 4);
     // ---- triangles: 64-B-strided intersection stream + 64-B shading stream ----
-    uint32_t n_slots = 0;
-    for (uint32_t i = 0; i < desc->n_tris; i++) if (slot_of_tri[i] + 1u > n_slots) n_slots = slot_of_tri[i] + 1u;
     if (n_slots > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, "%u triangle slots exceed the 2^25 device-format limit", n_slots);
     std::vector<float4> tri_pos((size_t)n_slots * mipt::kTriPosStride / 16 + 1, make_float4(0, 0, 0, 0));   // +1: the kernel's unconditional 4th float4 load
     std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
@@ -362,6 +321,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
     s->device = device_id;
     s->max_leaf = max_leaf;
+    s->n_tris = desc->n_tris;
     int rc;
     {
         hipError_t e1 = hipMalloc(&s->d_geom, pairs_bytes + pos_bytes + 64);
@@ -553,10 +513,24 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     }
     pr.ovf = scene->d_ovf;
 
+    // MIPT_FLAG_TOUCHED (diagnostic, counting build only): one bit per 128-B line of [pairs | tri_pos] and of tri_attr
+    const bool touched = count && (opt->flags & MIPT_FLAG_TOUCHED) != 0 && opt->shading == 0;
+    const size_t geom_lines = ((size_t)scene->dev.geom_bytes + 127) / 128, attr_lines = (scene->n_tris + 1) / 2;
+    const size_t geom_words = (geom_lines + 31) / 32, attr_words = (attr_lines + 31) / 32;
+    pr.touched = nullptr; pr.touched_attr_base = (uint32_t)(geom_words * 32);
+    if (touched) {
+        if (!scene->d_touched) HIP_TRY(hipMalloc((void **)&scene->d_touched, (geom_words + attr_words) * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(scene->d_touched, 0, (geom_words + attr_words) * sizeof(uint32_t), stream));
+        pr.touched = scene->d_touched;
+    }
     HIP_TRY(hipMemsetAsync(scene->d_stats, 0, sizeof(mipt::DevStats), stream));
     HIP_TRY(hipEventRecord(scene->ev0, stream));
     HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, (int)opt->shading, (int)grid, stream));
     HIP_TRY(hipEventRecord(scene->ev1, stream));
+    if (touched) {
+        HIP_TRY(mipt::launch_popcount(scene->d_touched, geom_words, &scene->d_stats->touched_geom, stream));
+        HIP_TRY(mipt::launch_popcount(scene->d_touched + geom_words, attr_words, &scene->d_stats->touched_attr, stream));
+    }
     if (d_rgba8) HIP_TRY(mipt::launch_tonemap(d_hdr_rgb, (unsigned long long)opt->width * opt->height, 1.0f, d_rgba8, stream));
     mipt::DevStats hs;
     HIP_TRY(hipMemcpyAsync(&hs, scene->d_stats, sizeof hs, hipMemcpyDeviceToHost, stream));
@@ -572,6 +546,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
         stats->diag[0] = hs.d_iters; stats->diag[1] = hs.d_inner_lanes; stats->diag[2] = hs.d_leaf_lanes;
         stats->diag[3] = hs.d_iters_inner; stats->diag[4] = hs.d_iters_leaf; stats->diag[5] = hs.d_services;
         stats->diag[6] = hs.d_service_lanes; stats->diag[7] = hs.d_cycles_service; stats->diag[8] = hs.d_cycles_total; stats->diag[9] = hs.d_cycles_mem; stats->diag[10] = hs.d_cycles_tail;
+        stats->touched_lines[0] = hs.touched_geom; stats->touched_lines[1] = hs.touched_attr;
     }
     if (hs.stack_overflows)
         return fail(MIPT_ERR_STACK, "traversal stack overflowed %llu times (capacity %d; the reference panics at 32, ray.rs:85)",

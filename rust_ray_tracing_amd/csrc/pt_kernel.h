@@ -56,6 +56,7 @@ struct DevStats {                 // zeroed before every launch
     // iterations that ran the inner / leaf branch, service passes, lanes serviced
     unsigned long long d_iters, d_inner_lanes, d_leaf_lanes, d_iters_inner, d_iters_leaf, d_services, d_service_lanes;
     unsigned long long d_cycles_service, d_cycles_total, d_cycles_mem, d_cycles_tail;   // per-wave s_memtime cycles spent in service passes / alive
+    unsigned long long touched_geom, touched_attr;                                     // distinct 128-B lines read (MIPT_FLAG_TOUCHED)
 };
 
 struct DevParams {
@@ -76,6 +77,8 @@ struct DevParams {
     float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
     uint32_t *ovf;                          // traversal-stack overflow area [wave][entry][lane]
     DevStats *stats;
+    uint32_t *touched;                      // COUNT build + MIPT_FLAG_TOUCHED: one bit per 128-B line of [geom | tri_attr] (else NULL)
+    uint32_t touched_attr_base;             // first bit of the tri_attr stream in `touched`
 };
 
 constexpr int kStackLds = 16;               // per-lane traversal-stack entries held in LDS
@@ -98,6 +101,8 @@ hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,
                           uint8_t *rgba8, hipStream_t stream);
 
+// number of set bits in words [0, n_words) of `bitmap`, added to *out (a device counter)
+hipError_t launch_popcount(const uint32_t *bitmap, unsigned long long n_words, unsigned long long *out, hipStream_t stream);
 hipError_t launch_divide(float *hdr, unsigned long long n_floats, float divisor, hipStream_t stream);
 hipError_t launch_postprocess(const float *hdr, unsigned long long n_pixels, float divisor, uint16_t *rgba16,
                               hipStream_t stream);

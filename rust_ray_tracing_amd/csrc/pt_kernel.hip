@@ -384,6 +384,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
                     const uint32_t tri = best_tri & ~kFrontBit;
                     const float4 a0 = sc.tri_attr[(size_t)tri * 4 + 0], a1 = sc.tri_attr[(size_t)tri * 4 + 1];
                     const float4 a2 = sc.tri_attr[(size_t)tri * 4 + 2], a3 = sc.tri_attr[(size_t)tri * 4 + 3];
+                    if (COUNT && pr.touched) { const uint32_t b = pr.touched_attr_base + (tri >> 1); atomicOr(&pr.touched[b >> 5], 1u << (b & 31u)); }
                     const float u = best_u, v = best_v;
                     const float w = 1.0f - u - v;                                   // ray.rs:45
                     V3 normal = mk(a0.x, a0.y, a0.z) * w + mk(a0.w, a1.x, a1.y) * u + mk(a1.z, a1.w, a2.x) * v;
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
             float4 r0, r1, r2, r3;
             r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
             r3 = ldg4(geom, voff + 48u);                                 // tri_pos is padded by one float4
+            if (COUNT && pr.touched) atomicOr(&pr.touched[voff >> 12], 1u << ((voff >> 7) & 31u));   // 128-B line voff / 128
             // Keep all four 16-B loads in front of the inner/leaf branch: without this barrier LLVM sinks the last
             // two into the inner branch, i.e. a second dependent memory round trip per step (measured: -10 % time).
             asm volatile("" ::: "memory");
@@ -701,6 +703,19 @@ __global__ void unpack_tiles_kernel(const float *__restrict__ packed_all, uint32
 }
 
 // ---- cpu.rs:60 on a reduced sum buffer: final_color /= samples (sample-sharded renders divide once, after the reduce) ----
+__global__ void popcount_kernel(const uint32_t *__restrict__ bitmap, unsigned long long n_words, unsigned long long *out) {
+    unsigned long long c = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        c += (unsigned long long)__popc(bitmap[i]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63u) == 0u && c) atomicAdd(out, c);
+}
+hipError_t launch_popcount(const uint32_t *bitmap, unsigned long long n_words, unsigned long long *out, hipStream_t stream) {
+    hipLaunchKernelGGL(popcount_kernel, dim3(1024), dim3(256), 0, stream, bitmap, n_words, out);
+    return hipGetLastError();
+}
+
 __global__ void divide_kernel(float *__restrict__ hdr, unsigned long long n_floats, float divisor) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_floats;
          i += (unsigned long long)gridDim.x * blockDim.x)

@@ -62,7 +62,7 @@ def test_no_oracle_or_cpu_fallback_linked(rrt):
 def test_struct_sizes_match_header(rrt):
     from rust_ray_tracing_amd import _lib as L
     assert C.sizeof(L.MiptOptions) == 16 * 4
-    assert C.sizeof(L.MiptStats) == 8 + 20 * 8
+    assert C.sizeof(L.MiptStats) == 8 + 22 * 8          # ABI v3: + touched_lines[2]
     assert C.sizeof(L.MiptSceneDesc) == 4 * 16
     assert C.sizeof(L.MiptTexture) == 16
 

@@ -93,3 +93,21 @@ def test_config5_4096_one_ranks_128spp_share(rrt, orc, atrium10m):
     assert np.array_equal(o.reshape(-1, 3)[idx].view(np.uint32), got[idx].view(np.uint32))
     assert float(np.isfinite(got).mean()) == 1.0
     print(f"config5 share: {st['kernel_ms']:.0f} ms for {w}x{h}x{share} spp, oracle sample {len(idx)} px / {ost['rays']} rays")
+
+
+def test_config_M_culled_traversal_renders_the_reference_traversals_frame(rrt, atrium10m):
+    """The metric's configuration (1920x1080, 8 spp, depth 64) on the 10 M-triangle scene: the recommended arm -- best-hit culling with
+    the 2^-7 relative margin (rt_compute.wgsl:341-349 + margin) -- must produce the frame of the CPU backend's own un-culled traversal
+    (reference src/renderer/backend/cpu/ray.rs:69-81, the Renderer default), all 2 073 600 pixels bit for bit, while visiting fewer
+    nodes.  (bench.py re-checks the same identity on every run; INTEGRATION.md recommends the culled arm on this evidence.)"""
+    import torch
+    from rust_ray_tracing_amd import _lib as L
+    sc = atrium10m
+    w, h, spp, depth = 1920, 1080, 8, 64
+    ref, rst = _device_render(rrt, sc, rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_REFERENCE, flags=L.FLAG_COUNT), w * h * 3)
+    cul, cst = _device_render(rrt, sc, rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_CULLED, cull_margin=L.CULL_MARGIN_SAFE,
+                                                        flags=L.FLAG_COUNT), w * h * 3)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int32), cul.view(torch.int32))
+    assert rst["rays"] == cst["rays"] and rst["hits"] == cst["hits"] and rst["pixels"] == w * h
+    assert cst["inner_steps"] < 0.7 * rst["inner_steps"] and cst["tri_tests"] <= rst["tri_tests"]

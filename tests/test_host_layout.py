@@ -184,3 +184,39 @@ def test_shared_child_bvh_is_refused_quickly(rrt):
     d = sc.desc()
     assert lib.mipt_scene_create(C.byref(d), 0, C.byref(h)) == L.ERR_BVH
     assert b"more than one leaf" in lib.mipt_last_error()
+
+
+def _slots(rrt, nodes, n_tris):
+    fn = rrt.load().mipt_internal_tri_slots
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+    fn.restype = C.c_int
+    out = np.zeros(n_tris, dtype=np.uint32)
+    n = C.c_uint32(0)
+    assert fn(nodes.ctypes.data, len(nodes), n_tris, out.ctypes.data, C.byref(n)) == 0
+    return out, n.value
+
+
+@pytest.mark.parametrize("kind,kw", [("cornell", {}), ("helmet", dict(n_target=3000, tex_size=8)), ("atrium", dict(n_target=20000, tex_size=8)),
+                                     ("dragon", dict(n_target=20000))])
+def test_triangle_slots(rrt, kind, kw):
+    """The device's intersection stream (mipt_internal_tri_slots): a permutation without holes; a leaf's triangles consecutive;
+    a 2-triangle leaf and the two 1-triangle leaves of one pair never straddle a 128-B line (two 64-B records per line)."""
+    from rust_ray_tracing_amd import synth
+    tris = synth.make_scene(kind, **kw)[0]
+    sc = rrt.Scene.from_arrays(tris, [rrt.material_default()])
+    nodes, n_tris = sc.bvh_nodes, len(sc.tris)
+    slot, n_slots = _slots(rrt, nodes, n_tris)
+    assert n_slots == n_tris and sorted(slot.tolist()) == list(range(n_tris))
+    doubles = 0
+    for k in range((len(nodes) - 1) // 2):
+        l, r = nodes[2 * k + 1], nodes[2 * k + 2]
+        for n in (l, r):
+            if n["num_tris"] > 0:
+                a, c = int(n["first_tri_or_child"]), int(n["num_tris"])
+                assert (slot[a:a + c] == slot[a] + np.arange(c)).all()                     # consecutive
+                if c == 2:
+                    assert slot[a] % 2 == 0; doubles += 1
+        if l["num_tris"] == 1 and r["num_tris"] == 1:
+            a = int(l["first_tri_or_child"])
+            assert int(r["first_tri_or_child"]) == a + 1 and slot[a] % 2 == 0 and slot[a + 1] == slot[a] + 1; doubles += 1
+    assert doubles > 0 or n_tris < 16
