@@ -486,12 +486,12 @@ def main():
         mats_arr = scene.materials_array()
         seed_mode = 0 if mode == "tiles" else 1
 
-        def cpu(stride, threads=0):
+        def cpu(stride, threads=0, spread=0):
             return orc.render(scene.tris, scene.bvh_nodes, mats_arr, scene.textures, scene.camera.uniform, w, h, spp, depth,
-                              cull=0, pix_stride=stride, want_rgba8=False, threads=threads, seed_mode=seed_mode)
+                              cull=0, pix_stride=stride, want_rgba8=False, threads=threads, seed_mode=seed_mode, spread_pages=spread)
         _, _, ps = cpu(8191)
         rate = ps["rays"] / max(ps["seconds"], 1e-6)
-        want_rays = rate * args.cpu_seconds / 2
+        want_rays = rate * args.cpu_seconds / 3
         stride = max(1, int(tot["rays"] / max(want_rays, 1))) | 1   # odd stride: samples every image column
         hdr_cpu, _, cs = cpu(stride)
 
@@ -506,8 +506,13 @@ def main():
                                   "sample": f"every {stride}th pixel of the same frame ({cs['rays']} rays, {cs['seconds']:.1f} s), "
                                             "C restatement of the reference's rayon backend (no t-max cull), all samples and bounces, "
                                             "uniform contiguous pixel blocks as cpu.rs:22-26",
+                                  "memory_placement": "reference-faithful: the scene arrays are allocated and filled by ONE thread (the reference builds its "
+                                                      "Vecs on the main thread, scene.rs:44-85), so on a multi-socket host every page sits on one NUMA node; "
+                                                      "numa_spread_run is the same sample with the pages first-touched share by share by the worker threads",
                                   "per_thread_mray_s": head["per_thread_mray_s"],
                                   "slowest_block_over_mean_block": head["slowest_block_over_mean_block"]}
+        _, _, cn = cpu(stride, spread=1)
+        result["cpu_baseline"]["numa_spread_run"] = summary(cn)
         if phys and phys != cs["threads_used"]:
             _, _, cp = cpu(stride, threads=phys)
             result["cpu_baseline"]["physical_cores_run"] = summary(cp)

@@ -25,7 +25,7 @@ class OrcOptions(C.Structure):
                 ("seed_mode", C.c_uint32), ("cull", C.c_uint32), ("libm", C.c_uint32), ("threads", C.c_uint32),
                 ("pix_begin", C.c_uint64), ("pix_end", C.c_uint64), ("pix_stride", C.c_uint32),
                 ("sample_begin", C.c_uint32), ("stack_cap", C.c_uint32), ("sum_only", C.c_uint32),
-                ("cull_margin", C.c_float), ("shading", C.c_uint32)]
+                ("cull_margin", C.c_float), ("shading", C.c_uint32), ("spread_pages", C.c_uint32)]
 
 
 class OrcStats(C.Structure):
@@ -157,7 +157,7 @@ def camera_from_pose(position, pitch, yaw) -> np.ndarray:
 
 def render(tris, nodes, materials, textures, camera, width, height, samples, max_ray_depth, *, seed_mode=0, cull=0,
            libm=LIBM_GLIBC235, threads=0, pix_begin=0, pix_end=0, pix_stride=0, sample_begin=0, sum_only=0, stack_cap=0,
-           cull_margin=0.0, shading=0, want_rgba8=True):
+           cull_margin=0.0, shading=0, want_rgba8=True, spread_pages=0):
     """Returns (hdr [h,w,3] f32, rgba8 [h,w,4] u8 | None, stats dict).  Arrays may be any dtype of the right byte size."""
     tris = np.ascontiguousarray(tris)
     nodes = np.ascontiguousarray(nodes)
@@ -165,7 +165,7 @@ def render(tris, nodes, materials, textures, camera, width, height, samples, max
     camera = np.ascontiguousarray(camera)
     textures = [np.ascontiguousarray(t) for t in textures]
     opt = OrcOptions(width, height, samples, max_ray_depth, seed_mode, cull, libm, threads, pix_begin, pix_end, pix_stride,
-                     sample_begin, stack_cap, sum_only, cull_margin, shading)
+                     sample_begin, stack_cap, sum_only, cull_margin, shading, spread_pages)
     hdr = np.zeros((height, width, 3), dtype=np.float32)
     rgba = np.zeros((height, width, 4), dtype=np.uint8) if want_rgba8 else None
     st = OrcStats()

@@ -12,6 +12,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sys/mman.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -729,6 +730,17 @@ uint64_t orc_visit_log(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *
     return cx.vlog_n;
 }
 
+typedef struct { const char *src_a; char *dst_a; size_t n_a; const char *src_b; char *dst_b; size_t n_b; uint32_t i, T; } SpreadJob;
+static void *spread_worker(void *arg) {       /* copies share i of T of both arrays (page-aligned cuts): first touch = this thread */
+    const SpreadJob *j = (const SpreadJob *)arg;
+    const size_t pg = 4096;
+    size_t lo = (j->n_a / j->T * j->i) / pg * pg, hi = (j->i + 1 == j->T) ? j->n_a : (j->n_a / j->T * (j->i + 1)) / pg * pg;
+    if (hi > lo) memcpy(j->dst_a + lo, j->src_a + lo, hi - lo);
+    lo = (j->n_b / j->T * j->i) / pg * pg; hi = (j->i + 1 == j->T) ? j->n_b : (j->n_b / j->T * (j->i + 1)) / pg * pg;
+    if (hi > lo) memcpy(j->dst_b + lo, j->src_b + lo, hi - lo);
+    return NULL;
+}
+
 int orc_render(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, uint32_t n_nodes,
                const OrcMaterial *materials, uint32_t n_materials,
                const OrcTexture *textures, uint32_t n_textures,
@@ -754,13 +766,31 @@ int orc_render(const OrcTriangle *tris, uint32_t n_tris, const OrcNode *nodes, u
     if (T > 1024) T = 1024;
     job.block = job.n_items / T; if (job.block == 0) job.block = 1;      /* cpu.rs:22 */
     pthread_mutex_init(&job.mu, NULL);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
+    /* spread_pages: copies of the two big arrays whose pages are first touched by the worker threads, share by share */
+    void *cp_tris = NULL, *cp_nodes = NULL;
+    const size_t tris_bytes = (size_t)n_tris * sizeof(OrcTriangle), nodes_bytes = (size_t)n_nodes * sizeof(OrcNode);
+    if (opt->spread_pages) {
+        cp_tris = mmap(NULL, tris_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        cp_nodes = mmap(NULL, nodes_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (cp_tris == MAP_FAILED || cp_nodes == MAP_FAILED) { free(th); return -6; }
+        SpreadJob *sj = (SpreadJob *)malloc(sizeof(SpreadJob) * T);
+        for (uint32_t i = 0; i < T; i++) {
+            sj[i] = (SpreadJob){(const char *)tris, (char *)cp_tris, tris_bytes, (const char *)nodes, (char *)cp_nodes, nodes_bytes, i, T};
+            pthread_create(&th[i], NULL, spread_worker, &sj[i]);
+        }
+        for (uint32_t i = 0; i < T; i++) pthread_join(th[i], NULL);
+        free(sj);
+        job.sc.tris = (const OrcTriangle *)cp_tris; job.sc.nodes = (const OrcNode *)cp_nodes;
+    }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
     for (uint32_t i = 0; i < T; i++) pthread_create(&th[i], NULL, worker, &job);
     for (uint32_t i = 0; i < T; i++) pthread_join(th[i], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     free(th);
+    if (cp_tris) munmap(cp_tris, tris_bytes);
+    if (cp_nodes) munmap(cp_nodes, nodes_bytes);
     pthread_mutex_destroy(&job.mu);
     if (stats) {
         *stats = job.total;

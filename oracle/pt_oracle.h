@@ -84,6 +84,10 @@ typedef struct {
     uint32_t sum_only;               /* 1: hdr = sum over samples (no /samples), for sample-sharding */
     float    cull_margin;            /* cull=1: skip a child iff !(t_near < best*(1+margin)); 0 = the WGSL rule */
     uint32_t shading;                /* 0 = cpu/ray.rs trace; 1 = rt_compute.wgsl trace (GGX/Fresnel/refraction/RR; per-sample seeds) */
+    uint32_t spread_pages;           /* timing aid (bench.py cpu_baseline): 0 = read the caller's arrays where they lie -- the reference's
+                                      * `Vec`s are allocated and filled by the main thread (scene.rs:44-85), so on a multi-socket host all
+                                      * pages sit on one NUMA node; 1 = first copy tris and nodes into fresh mappings, each worker thread
+                                      * copying (first-touching) one 1/T share, so the pages spread over the nodes the workers run on */
 } OrcOptions;
 
 typedef struct {

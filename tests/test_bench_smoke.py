@@ -35,6 +35,8 @@ def test_bench_json_contract(built):
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["per_thread_mray_s"] > 0 and cb["slowest_block_over_mean_block"] >= 1.0
+    assert "scene.rs:44-85" in cb["memory_placement"] and cb["numa_spread_run"]["value"] > 0
+    assert rf["unique_line_bytes"] > 0 and rf["unique_lines"]["triangle_attributes"] > 0 and "memside_frac_measured" in rf
     assert r["parity"]["culled_equals_reference_traversal"] is True and r["parity"]["oracle_bit_exact_on_sample"] is True
     assert "glibc" in r["parity"]["against"]
     assert r["render_multi"]["equals_bench_frame"] is True and r["render_multi"]["n_devices"] == 1 and r["render_multi"]["collective_ms"] > 0
