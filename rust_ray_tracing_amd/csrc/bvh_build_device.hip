@@ -34,16 +34,27 @@ namespace {
 constexpr int kT = 256;
 constexpr float F32_MAX = FLT_MAX;
 constexpr uint32_t kNone = 0xffffffffu;
-constexpr uint32_t kBig = 32768;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
-constexpr uint32_t kChunk = 8192;
+constexpr uint32_t kSubFlag = 0x80000000u;   // BNode::left = kSubFlag | pool index: the node's whole subtree lives in the pool (build_subtree_tiny)
+#ifndef MIPT_BVH_BIG
+#define MIPT_BVH_BIG 32768
+#endif
+#ifndef MIPT_BVH_CHUNK
+#define MIPT_BVH_CHUNK 8192
+#endif
+#ifndef MIPT_BVH_WAVEMAX
+#define MIPT_BVH_WAVEMAX 512
+#endif
+constexpr uint32_t kBig = MIPT_BVH_BIG;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
+constexpr uint32_t kChunk = MIPT_BVH_CHUNK;
+constexpr uint32_t kSub = 8;               // nodes this small: ONE thread finishes the whole subtree (build_subtree_tiny)
 constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
-constexpr uint32_t kWaveMax = 512;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
-enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3 };
+constexpr uint32_t kWaveMax = MIPT_BVH_WAVEMAX;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
+enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3, CLS_SUB = 4 };
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
 // children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
-struct Ctrl { uint32_t n_nodes; uint32_t n_chunks; uint32_t cnt[2][4]; };
-struct Lists { uint32_t *l[2][4]; };
+struct Ctrl { uint32_t n_nodes; uint32_t n_chunks; uint32_t cnt[2][5]; uint32_t pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
+struct Lists { uint32_t *l[2][5]; };
 
 struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
 struct BNode {
@@ -67,7 +78,7 @@ __device__ __forceinline__ float box_area(const float *lo, const float *hi) {   
 // Queue the two children of every active lane for the next level.  One atomic per class per wave: the lanes are ranked
 // with ballots (a per-lane atomicAdd on a per-lane class counter is not aggregated by the compiler and serialises in L2:
 // measured 30x slower on the deep levels).  Works under divergence -- only the lanes that reach this point take part.
-__device__ __forceinline__ uint32_t node_class(uint32_t n) { return n > kBig ? (uint32_t)CLS_BIG : (n > kWaveMax ? (uint32_t)CLS_BLOCK : (n > kTiny ? (uint32_t)CLS_WAVE : (uint32_t)CLS_TINY)); }
+__device__ __forceinline__ uint32_t node_class(uint32_t n) { return n > kBig ? (uint32_t)CLS_BIG : (n > kWaveMax ? (uint32_t)CLS_BLOCK : (n > kTiny ? (uint32_t)CLS_WAVE : (n > kSub ? (uint32_t)CLS_TINY : (uint32_t)CLS_SUB))); }
 __device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -77,7 +88,7 @@ __device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint
     const int leader = (int)__ffsll((long long)active) - 1;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
+    for (uint32_t c = 0; c < 5u; c++) {
         const unsigned long long ma = __ballot(ca == c), mb = __ballot(cb == c);
         const uint32_t tot = (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
         if (tot == 0u) continue;
@@ -628,6 +639,128 @@ __global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, u
                   Box3{b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]}, nd.first, k, n);
 }
 
+// ---- nodes with <= kSub triangles: one thread builds the node's WHOLE subtree (round 3) --------------------------------
+// The level-synchronous scheme spent most of its time here: one launch, one host read-back and one pass over global memory per
+// tree level for nodes that hold a handful of triangles (31 levels at 10 M triangles, the last ~12 of them nothing but such nodes).
+// Now the thread that reaches a node with <= 16 triangles loads its proxies into LDS ([slot][word][thread]: conflict-free) and
+// runs the reference's recursion to the end -- split_node (bvh.rs:56-136) with evaluate_sah (:138-161) as written, the partition
+// loop (:99-108) in place, children pushed in pairs and then left before right (:131-135) -- with an explicit stack.  The
+// subtree's nodes go to a pool in exactly the order the reference appends them, so their final indices are base(X) + local index
+// (desc(X) = [A, B] ++ desc(A) ++ desc(B)); sizes_level / bases_level treat X as a node with `size` descendants and emit_nodes
+// copies the pool block with its child indices re-based.  A child's box is recomputed from its range when the child is popped:
+// the same min/max over the same proxies in the same order as the parent's own child-box loops (bvh.rs:115-130), so the same bits.
+struct PoolNode { float lo[3]; uint32_t a; float hi[3]; uint32_t n; };            // a: local index of the left child (inner) / first triangle (leaf)
+constexpr uint32_t kSubRoot = 0xffffu;
+
+__global__ __launch_bounds__(64) void build_subtree_tiny(BNode *bn, const uint32_t *__restrict__ list, uint32_t count, const Proxy *pin,
+                                                         Proxy *pa, Proxy *pb, PoolNode *__restrict__ pool, Ctrl *ctrl) {   // pin is pa or pb
+    __shared__ float s_p[kSub][7][64];                    // lo.xyz, hi.xyz, idx (as bits); the centroid is (lo + hi) / 2 recomputed (scene.rs:125)
+    __shared__ uint32_t s_st[kSub + 1][64];
+    const uint32_t t = threadIdx.x, item = blockIdx.x * 64u + t;
+    const bool act = item < count;
+    uint32_t node_i = 0, n0 = 0, first0 = 0;
+    if (act) {
+        node_i = list[item];
+        n0 = bn[node_i].n; first0 = bn[node_i].first;
+        for (uint32_t i = 0; i < n0; i++) {
+            const Proxy p = pin[first0 + i];
+            for (int q = 0; q < 3; q++) { s_p[i][q][t] = p.lo[q]; s_p[i][3 + q][t] = p.hi[q]; }
+            s_p[i][6][t] = __uint_as_float(p.idx);
+        }
+    }
+    // pool space for the most nodes n0 triangles can make (2 n0 - 2), one atomic per wave
+    uint32_t need = act ? 2u * n0 - 2u : 0u, pre = need;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pre, o); if (t >= (uint32_t)o) pre += y; }
+    uint32_t base = 0;
+    if (t == 63u) base = atomicAdd(&ctrl->pool_alloc, pre);
+    base = __shfl(base, 63) + pre - need;
+    if (!act) return;
+
+    auto cen = [&](uint32_t i, int a) { return (s_p[i][a][t] + s_p[i][3 + a][t]) / 2.0f; };
+    uint32_t cnt = 0, sp = 0;
+    s_st[sp++][t] = 0u | (n0 << 8) | (kSubRoot << 16);
+    while (sp > 0u) {
+        const uint32_t e = s_st[--sp][t];
+        const uint32_t f = e & 255u, n = (e >> 8) & 255u, li = e >> 16;
+        float lo[3] = {F32_MAX, F32_MAX, F32_MAX}, hi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+        for (uint32_t i = f; i < f + n; i++)
+            for (int q = 0; q < 3; q++) { lo[q] = fminf(lo[q], s_p[i][q][t]); hi[q] = fmaxf(hi[q], s_p[i][3 + q][t]); }
+        if (li == kSubRoot) {                                // the subtree's root already has its box (from its parent: the same loop)
+            const BNode nd = bn[node_i];
+            for (int q = 0; q < 3; q++) { lo[q] = nd.lo[q]; hi[q] = nd.hi[q]; }
+        }
+        const float parent_cost = (float)n * box_area(lo, hi);
+        int best_axis = 0;
+        float best_pos = 0.0f, best_cost = F32_MAX;
+        for (int a = 0; a < 3; a++) {
+            float cmin = F32_MAX, cmax = -F32_MAX;
+            for (uint32_t i = f; i < f + n; i++) { const float c = cen(i, a); cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); }
+            if (cmin == cmax) continue;
+            const float scale = (cmax - cmin) / 8.0f;
+            for (int i = 1; i < 8; i++) {
+                const float pos = cmin + (float)i * scale;
+                float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+                float rlo[3] = {F32_MAX, F32_MAX, F32_MAX}, rhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+                uint32_t lc = 0, rc = 0;
+                for (uint32_t j = f; j < f + n; j++) {                                        // evaluate_sah, bvh.rs:138-161
+                    const bool left = cen(j, a) < pos;
+                    for (int q = 0; q < 3; q++) {
+                        const float pl = s_p[j][q][t], ph = s_p[j][3 + q][t];
+                        if (left) { llo[q] = fminf(llo[q], pl); lhi[q] = fmaxf(lhi[q], ph); }
+                        else { rlo[q] = fminf(rlo[q], pl); rhi[q] = fmaxf(rhi[q], ph); }
+                    }
+                    if (left) lc++; else rc++;
+                }
+                const float cost = (float)lc * box_area(llo, lhi) + (float)rc * box_area(rlo, rhi);
+                const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
+                if (split_cost < best_cost) { best_axis = a; best_pos = pos; best_cost = split_cost; }
+            }
+        }
+        bool split = !(best_cost >= parent_cost);                                              // bvh.rs:94
+        uint32_t k = 0;
+        if (split) {
+            uint32_t i = f, j = f + n - 1u;                                                    // bvh.rs:99-108, in place
+            while (i <= j) {
+                if (cen(i, best_axis) < best_pos) i++;
+                else {
+                    for (int w = 0; w < 7; w++) { const float x = s_p[i][w][t]; s_p[i][w][t] = s_p[j][w][t]; s_p[j][w][t] = x; }
+                    if (j == 0u) break;
+                    j--;
+                }
+            }
+            k = i - f;
+            if (k == 0u || k == n) split = false;                                              // bvh.rs:110-113
+        }
+        PoolNode out;
+        for (int q = 0; q < 3; q++) { out.lo[q] = lo[q]; out.hi[q] = hi[q]; }
+        if (split) {
+            out.a = cnt; out.n = 0u;
+            s_st[sp++][t] = (f + k) | ((n - k) << 8) | ((cnt + 1u) << 16);                       // right child: after the whole left subtree
+            s_st[sp++][t] = f | (k << 8) | (cnt << 16);
+            cnt += 2u;
+        } else {
+            out.a = first0 + f; out.n = n;
+        }
+        if (li != kSubRoot) pool[base + li] = out;
+        else if (split) { bn[node_i].left = kSubFlag | base; bn[node_i].size = cnt; }          // size is final after the loop (below)
+    }
+    if (cnt) bn[node_i].size = cnt;
+    for (uint32_t i = 0; i < n0; i++) {                                                        // the range in its final order, in both ping-pong buffers
+        Proxy p;
+        for (int q = 0; q < 3; q++) { p.lo[q] = s_p[i][q][t]; p.hi[q] = s_p[i][3 + q][t]; p.c[q] = (p.lo[q] + p.hi[q]) / 2.0f; }
+        p.idx = __float_as_uint(s_p[i][6][t]);
+        pa[first0 + i] = p; pb[first0 + i] = p;
+    }
+    {                                                                                          // subtree nodes made, one atomic per wave
+        uint32_t tot = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        const unsigned long long m = __ballot(true);
+        if (t == (uint32_t)(__ffsll((long long)m) - 1) && tot) atomicAdd(&ctrl->sub_nodes, tot);
+    }
+}
+
 // ---- nodes with > kBig triangles: the same five steps, spread over one workgroup per kChunk elements ---------------------
 struct BigState {
     uint32_t node;                 // BFS index
@@ -947,19 +1080,20 @@ __global__ void big_finish(const BigState *bs, BNode *bn, Ctrl *ctrl, Lists ls, 
 __global__ void sizes_level(BNode *bn, uint32_t begin, uint32_t end) {              // bottom-up: |desc(X)|
     for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
         const uint32_t l = bn[i].left;
+        if (l != kNone && (l & kSubFlag)) continue;                               // a finished subtree: size set by build_subtree_tiny
         bn[i].size = (l == kNone) ? 0u : 2u + bn[l].size + bn[l + 1].size;
     }
 }
 __global__ void bases_level(BNode *bn, uint32_t begin, uint32_t end) {              // top-down: desc(X) = [A, B] ++ desc(A) ++ desc(B)
     for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
         const uint32_t l = bn[i].left;
-        if (l == kNone) continue;
+        if (l == kNone || (l & kSubFlag)) continue;
         const uint32_t b = bn[i].base;
         bn[l].dfs = b; bn[l + 1].dfs = b + 1u;
         bn[l].base = b + 2u; bn[l + 1].base = b + 2u + bn[l].size;
     }
 }
-__global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, MiptNode *nodes) {
+__global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, const PoolNode *__restrict__ pool, MiptNode *nodes) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x) {
         const BNode b = bn[i];
         MiptNode nd;
@@ -967,6 +1101,16 @@ __global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, MiptNode *nodes) {
         if (b.left == kNone) { nd.first_tri_or_child = b.first; nd.num_tris = b.n; }
         else { nd.first_tri_or_child = b.base; nd.num_tris = 0; }
         nodes[b.dfs] = nd;
+        if (b.left != kNone && (b.left & kSubFlag)) {                              // its subtree: pool block -> nodes[base ...], child indices re-based
+            const PoolNode *src = pool + (b.left & ~kSubFlag);
+            for (uint32_t j = 0; j < b.size; j++) {
+                const PoolNode q = src[j];
+                MiptNode o;
+                o.bounds_min = {q.lo[0], q.lo[1], q.lo[2]}; o.bounds_max = {q.hi[0], q.hi[1], q.hi[2]};
+                o.first_tri_or_child = q.n ? q.a : b.base + q.a; o.num_tris = q.n;
+                nodes[b.base + j] = o;
+            }
+        }
     }
 }
 __global__ void gather_tris(const MiptTriangle *src, const Proxy *px, uint32_t n, MiptTriangle *dst) {
@@ -995,19 +1139,21 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     Proxy *d_px[2] = {nullptr, nullptr};
     BNode *d_bn = nullptr;
     MiptNode *d_nodes = nullptr;
+    PoolNode *d_pool = nullptr;
     uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
     Ctrl *d_ctrl = nullptr, *h_ctrl = nullptr;
     BigState *d_big = nullptr;
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t sb = nullptr, sw = nullptr, st = nullptr, sg = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
+    hipStream_t sb = nullptr, sw = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
         if (sb) (void)hipStreamDestroy(sb);
         if (sw) (void)hipStreamDestroy(sw);
         if (st) (void)hipStreamDestroy(st);
         if (sg) (void)hipStreamDestroy(sg);
-        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
+        if (ss) (void)hipStreamDestroy(ss);
+        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (h_ctrl) (void)hipHostFree(h_ctrl);
         if (e0) (void)hipEventDestroy(e0);
@@ -1022,6 +1168,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipMalloc((void **)&d_px[1], (size_t)n_tris * sizeof(Proxy)));
     HIP_TRY(hipMalloc((void **)&d_bn, (size_t)max_nodes * sizeof(BNode)));
     HIP_TRY(hipMalloc((void **)&d_nodes, (size_t)max_nodes * sizeof(MiptNode)));
+    HIP_TRY(hipMalloc((void **)&d_pool, (size_t)max_nodes * sizeof(PoolNode)));
     HIP_TRY(hipMalloc((void **)&d_hp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_ctrl, sizeof(Ctrl)));
@@ -1029,11 +1176,12 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     // work lists: a level has at most min(2^level, n_tris) nodes; a class list never holds more nodes than triangles / its
     // smallest node... sized by the simple bound n_tris + 1 per (parity, class)
     const size_t list_cap = (size_t)n_tris + 1u;
-    HIP_TRY(hipMalloc((void **)&d_lists, (6 * list_cap + 2 * (size_t)big_cap) * 4));
+    HIP_TRY(hipMalloc((void **)&d_lists, (8 * list_cap + 2 * (size_t)big_cap) * 4));
     Lists ls;
     for (int pa = 0; pa < 2; pa++) {
-        for (int c = 0; c < 3; c++) ls.l[pa][c] = d_lists + (size_t)(pa * 3 + c) * list_cap;
-        ls.l[pa][CLS_BIG] = d_lists + 6 * list_cap + (size_t)pa * big_cap;
+        for (int c = 0; c < 3; c++) ls.l[pa][c] = d_lists + (size_t)(pa * 4 + c) * list_cap;
+        ls.l[pa][CLS_SUB] = d_lists + (size_t)(pa * 4 + 3) * list_cap;
+        ls.l[pa][CLS_BIG] = d_lists + 8 * list_cap + (size_t)pa * big_cap;
     }
     HIP_TRY(hipMalloc((void **)&d_root, 24));
     HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
@@ -1045,6 +1193,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipStreamCreate(&sw));
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
+    HIP_TRY(hipStreamCreate(&ss));
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
@@ -1052,7 +1201,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     memset(&hc, 0, sizeof hc);
     hc.n_nodes = 1u;
     {                                                       // the root goes straight into its class list (parity 0)
-        const int cls = n_tris > kBig ? CLS_BIG : (n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : CLS_TINY));
+        const int cls = n_tris > kBig ? CLS_BIG : (n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : (n_tris > kSub ? CLS_TINY : CLS_SUB)));
         hc.cnt[0][cls] = 1u;
         const uint32_t zero = 0u;
         HIP_TRY(hipMemcpy(ls.l[0][cls], &zero, 4, hipMemcpyHostToDevice));
@@ -1085,22 +1234,25 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
             hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
             hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
         }
-        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK], nwav = hc.cnt[parity][CLS_WAVE], ntin = hc.cnt[parity][CLS_TINY];
+        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK], nwav = hc.cnt[parity][CLS_WAVE], ntin = hc.cnt[parity][CLS_TINY], nsub = hc.cnt[parity][CLS_SUB];
         if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kT), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
         if (nwav) hipLaunchKernelGGL(build_level_wave, dim3((nwav + (uint32_t)kWaveNodes - 1u) / (uint32_t)kWaveNodes), dim3(64 * kWaveNodes), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (nsub) hipLaunchKernelGGL(build_subtree_tiny, dim3((nsub + 63u) / 64u), dim3(64), 0, ss, d_bn, ls.l[parity][CLS_SUB], nsub, d_px[cur], d_px[0], d_px[1], d_pool, d_ctrl);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(h_ctrl, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));        // pinned target; also the level's barrier
         hc = *h_ctrl;
         const uint32_t total = hc.n_nodes;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = hc.cnt[parity][3] = 0u;   // this level's lists are consumed: reset for level + 2
-        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, 16, nullptr));           // stream-ordered, no host round trip
+        hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = hc.cnt[parity][3] = hc.cnt[parity][4] = 0u;   // this level's lists are consumed: reset for level + 2
+        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, 20, nullptr));           // stream-ordered, no host round trip
         begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
-    const uint32_t n_nodes = end;
-    lvl_begin.push_back(n_nodes);
+    const uint32_t n_bn = end;                                  // nodes built level by level; the finished subtrees' nodes live in the pool
+    const uint32_t n_nodes = n_bn + hc.sub_nodes;
+    lvl_begin.push_back(n_bn);
+    if (n_nodes > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
     if (n_nodes > nodes_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: nodes_cap too small"); return MIPT_ERR_INVALID_ARG; }
     for (int l = (int)lvl_begin.size() - 2; l >= 0; l--) {
         const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
@@ -1110,7 +1262,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
         hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
     }
-    hipLaunchKernelGGL(emit_nodes, dim3(2048), dim3(256), 0, nullptr, d_bn, n_nodes, d_nodes);
+    hipLaunchKernelGGL(emit_nodes, dim3(2048), dim3(256), 0, nullptr, d_bn, n_bn, d_pool, d_nodes);
     hipLaunchKernelGGL(gather_tris, dim3(4096), dim3(256), 0, nullptr, d_tris, d_px[cur], n_tris, d_out);
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
