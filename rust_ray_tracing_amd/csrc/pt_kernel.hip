@@ -714,6 +714,10 @@ constexpr int kRecAux = MIPT_REC_AUX;     // buffer cache policy of the path rec
                                           // i.e. one CU and one (write-through) L1; agent scope (sc1 = 16) measured 1.2x slower
 enum : uint32_t { L_IDLE = 0, L_T = 1, L_DONE = 2 };
 
+// path records, structure of arrays: vector v (16 B) of slot p at byte (v * kPaths + p) * 16.  The 64 lanes of a batch then read / write 64
+// neighbouring 16-B pieces per instruction -- 16 lines -- instead of one line each (array of structures: the address FIFO of the
+// memory pipe was full 6x as often as in the kernel above, tools/experiments/queue_kernel_counters.sh)
+__device__ __forceinline__ uint32_t rec_off(uint32_t p, uint32_t v) { return (v * kPaths + p) * 16u; }
 template <class R>
 __device__ __forceinline__ float4 rec_load(R rsrc, uint32_t byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, kRecAux);
@@ -728,8 +732,11 @@ __device__ __forceinline__ void rec_store(R rsrc, uint32_t byte_off, float4 f) {
 #ifndef MIPT_Q_TAIL_RULE
 #define MIPT_Q_TAIL_RULE 1
 #endif
+#ifndef MIPT_Q_MIN_WAVES
+#define MIPT_Q_MIN_WAVES 4          // the hit records live in LDS (39 KB per block): four blocks per CU
+#endif
 template <bool COUNT, bool CULL>
-__global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PER_SIMD : MIPT_MIN_WAVES_UNCULLED) void pt_trace_kernel_q(DevScene sc, DevParams pr) {
+__global__ __launch_bounds__(kBlockThreads, MIPT_Q_MIN_WAVES) void pt_trace_kernel_q(DevScene sc, DevParams pr) {
     __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];
     __shared__ double s_logtab[32];
     // Q_ray: the ready rays themselves, [field][entry] (o.xyz, d.xyz, rd.xyz, safe, path slot; 64 entries: a service pass only runs
@@ -737,6 +744,9 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
     // consumed before the pass writes its rays.
     __shared__ __attribute__((aligned(16))) float s_ring[kWavesPerBlock][11][64];
     __shared__ uint32_t s_qs[kWavesPerBlock][kPaths];
+    // the hit of a finished ray waits here for its shading pass ([field][slot]).  Through memory instead -- one 16-B store per iteration
+    // with one or two lanes active -- the kernel was bound by the memory pipe's address path (SQ_VMEM_TA_ADDR_FIFO_FULL 6x)
+    __shared__ float s_hit[kWavesPerBlock][4][kPaths];
     if (threadIdx.x < 32u) s_logtab[threadIdx.x] = gl_d(glibc_logf_tab, (int)threadIdx.x);
     __syncthreads();
 
@@ -745,17 +755,18 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
     uint32_t(*stk)[64] = s_stack[wib];
     float(*ring)[64] = s_ring[wib];
     uint32_t *qs = s_qs[wib];
+    float(*hit)[kPaths] = s_hit[wib];
     const uint32_t wave_g = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)kWavesPerBlock + wib);
     uint32_t *ovf = pr.ovf + (size_t)wave_g * (size_t)(kStackOvf * 64) + lane;
     const auto geom = __builtin_amdgcn_make_buffer_rsrc((void *)sc.pairs, 0, (int)sc.geom_bytes, 0x00020000);
-    // this wave's path records: slot p at byte p * 128 = {o, safe | d, sample | rd, bounces | t, u, v, tri | ray_color, rng |
+    // this wave's path records, 8 vectors per slot (rec_off): {o, safe | d, sample | rd, bounces | t, u, v, tri | ray_color, rng |
     // incoming, pix | emitted, slot | final_color, state}
     const auto recs = __builtin_amdgcn_make_buffer_rsrc((void *)(pr.path_rec + (size_t)wave_g * (kPaths * 8u)), 0, (int)(kPaths * 128u), 0x00020000);
 
     // every path slot starts in Q_shade asking for a pixel
     for (uint32_t i = lane; i < kPaths; i += 64u) {
         qs[i] = i;
-        rec_store(recs, i * 128u + 112u, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_P)));
+        rec_store(recs, rec_off(i, 7u), make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_P)));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -782,9 +793,7 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
             const unsigned long long m_done = __ballot(lstate == L_DONE);
             if (m_done != 0ull) {
                 if (lstate == L_DONE) {
-#ifndef MIPT_WHATIF_NO_HIT_STORE
-                    rec_store(recs, pid * 128u + 48u, make_float4(best_t, best_u, best_v, __uint_as_float(best_tri)));
-#endif
+                    hit[0][pid] = best_t; hit[1][pid] = best_u; hit[2][pid] = best_v; hit[3][pid] = __uint_as_float(best_tri);
                     qs[(qs_tail + lane_rank(m_done)) & (kPaths - 1u)] = pid;
                     lstate = L_IDLE;
                 }
@@ -823,7 +832,6 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
             if (COUNT) { g_serv++; g_serv_lanes += n_sh < 64u ? n_sh : 64u; g_t0 = clock64(); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the hit records of step A have reached the L2
             const uint32_t nb = n_sh < 64u ? n_sh : 64u;
             const bool act = lane < nb;
             uint32_t spid = 0, state = ST_X;
@@ -834,11 +842,10 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
             uint32_t h_tri = kNoTri;
             if (act) {
                 spid = qs[(qs_head + lane) & (kPaths - 1u)];
-                const uint32_t b = spid * 128u;
-                const float4 v0 = rec_load(recs, b), v1 = rec_load(recs, b + 16u), v2 = rec_load(recs, b + 32u), v3 = rec_load(recs, b + 48u);
-                const float4 v4 = rec_load(recs, b + 64u), v5 = rec_load(recs, b + 80u), v6 = rec_load(recs, b + 96u), v7 = rec_load(recs, b + 112u);
+                const float4 v0 = rec_load(recs, rec_off(spid, 0u)), v1 = rec_load(recs, rec_off(spid, 1u)), v2 = rec_load(recs, rec_off(spid, 2u));
+                const float4 v4 = rec_load(recs, rec_off(spid, 4u)), v5 = rec_load(recs, rec_off(spid, 5u)), v6 = rec_load(recs, rec_off(spid, 6u)), v7 = rec_load(recs, rec_off(spid, 7u));
                 so = mk(v0.x, v0.y, v0.z); sd = mk(v1.x, v1.y, v1.z); sample = __float_as_uint(v1.w); bounces = __float_as_uint(v2.w);
-                h_t = v3.x; h_u = v3.y; h_v = v3.z; h_tri = __float_as_uint(v3.w);
+                h_t = hit[0][spid]; h_u = hit[1][spid]; h_v = hit[2][spid]; h_tri = __float_as_uint(hit[3][spid]);
                 ray_color = mk(v4.x, v4.y, v4.z); rng = __float_as_uint(v4.w);
                 incoming = mk(v5.x, v5.y, v5.z); pix = __float_as_uint(v5.w);
                 emitted = mk(v6.x, v6.y, v6.z); slot = __float_as_uint(v6.w);
@@ -989,21 +996,20 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
             // ---- out: paths with a new ray -> record + Q_ray; paths still without a pixel -> back into Q_shade; the rest is done ----
             const bool to_ray = act && start_ray;
             const bool retry = act && state == ST_P;
-            if (retry) rec_store(recs, spid * 128u + 112u, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_P)));
+            if (retry) rec_store(recs, rec_off(spid, 7u), make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_P)));
             const unsigned long long m_r = __ballot(to_ray), m_b = __ballot(retry);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");            // the draws in the ring's memory have been read by every lane
             __builtin_amdgcn_wave_barrier();
             if (to_ray) {
                 const V3 srd = mk(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z);
                 const uint32_t safe = ray_safe(so, sd, sc.tiny_axes) ? 1u : 0u;
-                const uint32_t b = spid * 128u;
-                rec_store(recs, b, make_float4(so.x, so.y, so.z, __uint_as_float(safe)));
-                rec_store(recs, b + 16u, make_float4(sd.x, sd.y, sd.z, __uint_as_float(sample)));
-                rec_store(recs, b + 32u, make_float4(srd.x, srd.y, srd.z, __uint_as_float(bounces)));
-                rec_store(recs, b + 64u, make_float4(ray_color.x, ray_color.y, ray_color.z, __uint_as_float(rng)));
-                rec_store(recs, b + 80u, make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(pix)));
-                rec_store(recs, b + 96u, make_float4(emitted.x, emitted.y, emitted.z, __uint_as_float(slot)));
-                rec_store(recs, b + 112u, make_float4(final_color.x, final_color.y, final_color.z, __uint_as_float((uint32_t)ST_S)));
+                rec_store(recs, rec_off(spid, 0u), make_float4(so.x, so.y, so.z, __uint_as_float(safe)));
+                rec_store(recs, rec_off(spid, 1u), make_float4(sd.x, sd.y, sd.z, __uint_as_float(sample)));
+                rec_store(recs, rec_off(spid, 2u), make_float4(srd.x, srd.y, srd.z, __uint_as_float(bounces)));
+                rec_store(recs, rec_off(spid, 4u), make_float4(ray_color.x, ray_color.y, ray_color.z, __uint_as_float(rng)));
+                rec_store(recs, rec_off(spid, 5u), make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(pix)));
+                rec_store(recs, rec_off(spid, 6u), make_float4(emitted.x, emitted.y, emitted.z, __uint_as_float(slot)));
+                rec_store(recs, rec_off(spid, 7u), make_float4(final_color.x, final_color.y, final_color.z, __uint_as_float((uint32_t)ST_S)));
                 const uint32_t e = (qr_tail + lane_rank(m_r)) & 63u;
                 ring[0][e] = so.x; ring[1][e] = so.y; ring[2][e] = so.z;
                 ring[3][e] = sd.x; ring[4][e] = sd.y; ring[5][e] = sd.z;
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(kBlockThreads, (CULL && !COUNT) ? MIPT_MIN_WAVES_PE
             // the rays the lanes are in the middle of were not kept in registers across the pass (its f64 arithmetic needs them):
             // every lane re-reads o, d, 1/d of its path slot -- unconditionally, so that the old values are dead above
             {
-                const float4 v0 = rec_load(recs, pid * 128u), v1 = rec_load(recs, pid * 128u + 16u), v2 = rec_load(recs, pid * 128u + 32u);
+                const float4 v0 = rec_load(recs, rec_off(pid, 0u)), v1 = rec_load(recs, rec_off(pid, 1u)), v2 = rec_load(recs, rec_off(pid, 2u));
                 o = mk(v0.x, v0.y, v0.z); safe_bits = __float_as_uint(v0.w);
                 d = mk(v1.x, v1.y, v1.z); rd = mk(v2.x, v2.y, v2.z);
                 // wait for them HERE: with loads into o / d / rd still in flight at the loop head, step B (which overwrites the same
