@@ -20,6 +20,9 @@ ap.add_argument("--spp", type=int, default=8)
 ap.add_argument("--world", type=int, default=1, help="render only rank 0's tile share of this many ranks")
 ap.add_argument("--shading", type=int, default=0)
 ap.add_argument("--depth", type=int, default=64)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--seed-mode", type=int, default=0, help="1 = per-sample seeds (rt_compute.wgsl:102)")
 ap.add_argument("--traversal", type=int, default=1, help="0 = the CPU backend's un-culled traversal, 1 = culled (margin 2^-7)")
 ap.add_argument("--count", action="store_true", help="one extra counting launch: rays / inner steps / tri tests")
 ap.add_argument("libs", nargs="+")
@@ -30,7 +33,7 @@ sc = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
 del tris
 sc.build_bvh_device(0)
 sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
-w, h = 1920, 1080
+w, h = args.width, args.height
 n_out = int(rrt.load().mipt_packed_pixels(w, h, args.world)) if args.world > 1 else w * h
 buf = np.zeros(n_out * 3, dtype=np.float32)
 desc = sc.desc()
@@ -51,7 +54,7 @@ for spec in args.libs:
     assert rc == 0, lib.mipt_last_error()
     ts = []
     for rep in range(args.reps):
-        o = rrt.make_options(w, h, args.spp, args.depth, traversal=args.traversal, flags=L.FLAG_PACKED if args.world > 1 else 0, tile_rank=0,
+        o = rrt.make_options(w, h, args.spp, args.depth, seed_mode=args.seed_mode, traversal=args.traversal, flags=L.FLAG_PACKED if args.world > 1 else 0, tile_rank=0,
                              tile_world=args.world, shading=args.shading)
         st = L.MiptStats()
         rc = lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st))
@@ -59,7 +62,7 @@ for spec in args.libs:
         ts.append(st.kernel_ms)
     extra = ""
     if args.count:
-        o = rrt.make_options(w, h, args.spp, args.depth, traversal=args.traversal, flags=L.FLAG_COUNT | (L.FLAG_PACKED if args.world > 1 else 0), tile_rank=0,
+        o = rrt.make_options(w, h, args.spp, args.depth, seed_mode=args.seed_mode, traversal=args.traversal, flags=L.FLAG_COUNT | (L.FLAG_PACKED if args.world > 1 else 0), tile_rank=0,
                              tile_world=args.world, shading=args.shading)
         st = L.MiptStats()
         assert lib.mipt_render(hnd, L.ptr(sc.camera.uniform), C.byref(o), L.ptr(buf), None, C.byref(st)) == 0
