@@ -63,8 +63,6 @@ struct MiptScene {
     uint32_t *d_ovf = nullptr;
     size_t ovf_waves = 0;
     uint32_t *d_touched = nullptr;          // MIPT_FLAG_TOUCHED: line bitmap, allocated on first use
-    float4 *d_paths = nullptr;              // queue kernel: path records, sized with d_ovf
-    size_t path_waves = 0;
     size_t n_tris = 0;
     float *d_hdr = nullptr;
     size_t hdr_floats = 0;
@@ -81,7 +79,7 @@ void free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels,
-                    s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba, s->d_touched, s->d_paths};
+                    s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba, s->d_touched};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -483,11 +481,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
 
     const bool count = (opt->flags & MIPT_FLAG_COUNT) != 0;
     const bool cull = opt->traversal == MIPT_TRAVERSAL_CULLED;
-#ifndef MIPT_QUEUE_KERNEL
-#define MIPT_QUEUE_KERNEL 0
-#endif
-    const bool queue = MIPT_QUEUE_KERNEL != 0 && opt->shading == MIPT_SHADING_CPU;
-    const int occ = mipt::trace_blocks_per_cu(count, cull, (int)opt->shading, queue);
+    const int occ = mipt::trace_blocks_per_cu(count, cull, (int)opt->shading);
     int bpc = occ;
     // Small shards (multi-GPU tile split: fewer pixels than resident lanes) are bound by the longest per-pixel chain --
     // a pixel's samples are sequential on one RNG stream -- and each chain steps faster with fewer co-resident waves:
@@ -518,15 +512,6 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
         scene->ovf_waves = waves;
     }
     pr.ovf = scene->d_ovf;
-    pr.path_rec = nullptr;
-    if (queue) {
-        if (waves > scene->path_waves) {
-            if (scene->d_paths) { (void)hipFree(scene->d_paths); scene->d_paths = nullptr; scene->path_waves = 0; }
-            HIP_TRY(hipMalloc((void **)&scene->d_paths, waves * (size_t)mipt::kPaths * 128));
-            scene->path_waves = waves;
-        }
-        pr.path_rec = scene->d_paths;
-    }
 
     // MIPT_FLAG_TOUCHED (diagnostic, counting build only): one bit per 128-B line of [pairs | tri_pos] and of tri_attr
     const bool touched = count && (opt->flags & MIPT_FLAG_TOUCHED) != 0 && opt->shading == 0;
@@ -540,7 +525,7 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     }
     HIP_TRY(hipMemsetAsync(scene->d_stats, 0, sizeof(mipt::DevStats), stream));
     HIP_TRY(hipEventRecord(scene->ev0, stream));
-    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, (int)opt->shading, queue, (int)grid, stream));
+    HIP_TRY(mipt::launch_trace(scene->dev, pr, count, cull, (int)opt->shading, (int)grid, stream));
     HIP_TRY(hipEventRecord(scene->ev1, stream));
     if (touched) {
         HIP_TRY(mipt::launch_popcount(scene->d_touched, geom_words, &scene->d_stats->touched_geom, stream));

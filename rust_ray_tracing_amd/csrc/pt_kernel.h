@@ -77,7 +77,6 @@ struct DevParams {
     float *hdr;                             // full-frame or rank-packed, 3 f32 per pixel
     uint32_t *ovf;                          // traversal-stack overflow area [wave][entry][lane]
     DevStats *stats;
-    float4 *path_rec;                       // queue kernel: kPaths x 128-B path records per wave ([wave][path][8 float4])
     uint32_t *touched;                      // COUNT build + MIPT_FLAG_TOUCHED: one bit per 128-B line of [geom | tri_attr] (else NULL)
     uint32_t touched_attr_base;             // first bit of the tri_attr stream in `touched`
 };
@@ -90,17 +89,13 @@ constexpr int kWavesPerBlock = 4;
 #endif
 constexpr uint32_t kTriPosStride = MIPT_TRI_POS_STRIDE;   // bytes per record of the intersection stream: 48 packed, 64 = never straddles a 128-B line
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
-#ifndef MIPT_PATHS_PER_WAVE
-#define MIPT_PATHS_PER_WAVE 128
-#endif
-constexpr uint32_t kPaths = MIPT_PATHS_PER_WAVE;          // queue kernel: path slots per wave (a power of two >= 64): 64 in the lanes + the rest queued
 constexpr uint32_t kMaxTris = 1u << 25;     // stack-entry encoding: 25-bit triangle index
 constexpr uint32_t kMaxPairs = 1u << 24;    // 24-bit pair index in the child-ref form
 
 // Launchers (stream-ordered; no allocation, no synchronisation inside).
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int shading, bool queue,
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int shading,
                         int grid_blocks, hipStream_t stream);
-int trace_blocks_per_cu(bool count, bool cull, int shading, bool queue);     // occupancy query
+int trace_blocks_per_cu(bool count, bool cull, int shading);     // occupancy query
 hipError_t launch_unpack_tiles(const float *packed_all, uint32_t width, uint32_t height,
                                uint32_t tile_world, float *hdr, hipStream_t stream);
 hipError_t launch_tonemap(const float *hdr, unsigned long long n_pixels, float divisor,

@@ -694,469 +694,6 @@ __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? M
     if (c_pixels) atomicAdd(&pr.stats->pixels, (unsigned long long)c_pixels);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Queue variant of the CPU-backend kernel (round 3 experiment): the same traversal step and the same shading code, but a lane
-// no longer OWNS a pixel.  In the kernel above 38 of a wave's 64 lanes take an inner step per iteration: ~12 wait for the next
-// service pass (it runs when 3/8 of the live lanes ask for it), ~8 are held for the next leaf phase, the rest is tail -- and the
-// service pass itself runs with 22 lanes.  Here a wave has kPaths = 128 path slots in memory (128 B each: ray, hit, colours, RNG
-// word, pixel, sample, bounce) and two queues:
-//     Q_ray    the ready rays themselves in LDS  -> a lane that finishes a ray takes the next one at once
-//     Q_shade  slots whose ray has finished      -> shaded up to 64 at a time, every lane of the wave busy
-// A lane holds only the traversal state of ONE ray, so nothing is added to the register budget (colours, RNG word and pixel
-// bookkeeping are not live during traversal).  Both queues belong to one wave: heads and tails are wave-uniform registers, pushes
-// and pops are ballot + mbcnt -- no atomics, no cross-wave waiting, nothing that can deadlock.  Per path the sequence of
-// operations is exactly the one above (a path has at most one ray in flight, its samples run in order on its own RNG word), so
-// the frame and every counter are bit-identical.
-#ifndef MIPT_REC_AUX
-#define MIPT_REC_AUX 0
-#endif
-constexpr int kRecAux = MIPT_REC_AUX;     // buffer cache policy of the path records: 0 = default.  Writer and reader are lanes of ONE wave,
-                                          // i.e. one CU and one (write-through) L1; agent scope (sc1 = 16) measured 1.2x slower
-enum : uint32_t { L_IDLE = 0, L_T = 1, L_DONE = 2 };
-
-// path records, structure of arrays: vector v (16 B) of slot p at byte (v * kPaths + p) * 16.  The 64 lanes of a batch then read / write 64
-// neighbouring 16-B pieces per instruction -- 16 lines -- instead of one line each (array of structures: the address FIFO of the
-// memory pipe was full 6x as often as in the kernel above, tools/experiments/queue_kernel_counters.sh)
-__device__ __forceinline__ uint32_t rec_off(uint32_t p, uint32_t v) { return (v * kPaths + p) * 16u; }
-template <class R>
-__device__ __forceinline__ float4 rec_load(R rsrc, uint32_t byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, kRecAux);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-template <class R>
-__device__ __forceinline__ void rec_store(R rsrc, uint32_t byte_off, float4 f) {
-    u32x4 v; v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, kRecAux);
-}
-
-#ifndef MIPT_Q_TAIL_RULE
-#define MIPT_Q_TAIL_RULE 1
-#endif
-#ifndef MIPT_Q_MIN_WAVES
-#define MIPT_Q_MIN_WAVES 4          // the hit records live in LDS (39 KB per block): four blocks per CU
-#endif
-template <bool COUNT, bool CULL>
-__global__ __launch_bounds__(kBlockThreads, MIPT_Q_MIN_WAVES) void pt_trace_kernel_q(DevScene sc, DevParams pr) {
-    __shared__ uint32_t s_stack[kWavesPerBlock][kStackLds + 1][64];
-    __shared__ double s_logtab[32];
-    // Q_ray: the ready rays themselves, [field][entry] (o.xyz, d.xyz, rd.xyz, safe, path slot; 64 entries: a service pass only runs
-    // when the ring is empty and adds at most 64).  The scatter draws of a pass use the same memory (its first 6 fields): they are
-    // consumed before the pass writes its rays.
-    __shared__ __attribute__((aligned(16))) float s_ring[kWavesPerBlock][11][64];
-    __shared__ uint32_t s_qs[kWavesPerBlock][kPaths];
-    // the hit of a finished ray waits here for its shading pass ([field][slot]).  Through memory instead -- one 16-B store per iteration
-    // with one or two lanes active -- the kernel was bound by the memory pipe's address path (SQ_VMEM_TA_ADDR_FIFO_FULL 6x)
-    __shared__ float s_hit[kWavesPerBlock][4][kPaths];
-    if (threadIdx.x < 32u) s_logtab[threadIdx.x] = gl_d(glibc_logf_tab, (int)threadIdx.x);
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wib = threadIdx.x >> 6;
-    uint32_t(*stk)[64] = s_stack[wib];
-    float(*ring)[64] = s_ring[wib];
-    uint32_t *qs = s_qs[wib];
-    float(*hit)[kPaths] = s_hit[wib];
-    const uint32_t wave_g = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)kWavesPerBlock + wib);
-    uint32_t *ovf = pr.ovf + (size_t)wave_g * (size_t)(kStackOvf * 64) + lane;
-    const auto geom = __builtin_amdgcn_make_buffer_rsrc((void *)sc.pairs, 0, (int)sc.geom_bytes, 0x00020000);
-    // this wave's path records, 8 vectors per slot (rec_off): {o, safe | d, sample | rd, bounces | t, u, v, tri | ray_color, rng |
-    // incoming, pix | emitted, slot | final_color, state}
-    const auto recs = __builtin_amdgcn_make_buffer_rsrc((void *)(pr.path_rec + (size_t)wave_g * (kPaths * 8u)), 0, (int)(kPaths * 128u), 0x00020000);
-
-    // every path slot starts in Q_shade asking for a pixel
-    for (uint32_t i = lane; i < kPaths; i += 64u) {
-        qs[i] = i;
-        rec_store(recs, rec_off(i, 7u), make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_P)));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t qr_head = 0, qr_tail = 0, qs_head = 0, qs_tail = kPaths;   // wave-uniform, monotonic (indices taken mod 64 / mod kPaths)
-
-    // ---- per-lane traversal state: ONE ray ----
-    uint32_t lstate = L_IDLE, pid = 0;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), rd = mk(0, 0, 1);
-    uint32_t safe_bits = 0;                                    // ray_safe(o, d) of the lane's ray, as stored by the service pass
-    float best_t = kMiss, best_u = 0, best_v = 0;
-    uint32_t best_tri = kNoTri;
-    uint32_t tri_cur = 0, tri_end = 0, pair = 0, sp = 0;
-    unsigned long long c_rays = 0, c_inner = 0, c_tris = 0, c_hits = 0, c_tex = 0;
-    uint32_t c_maxsp = 0, c_pixels = 0;
-    unsigned long long g_iters = 0, g_inner = 0, g_leaf = 0, g_it_inner = 0, g_it_leaf = 0, g_serv = 0, g_serv_lanes = 0;
-    unsigned long long g_t_serv = 0, g_t_start = COUNT ? clock64() : 0ull, g_t0 = 0, g_t_first_x = 0;
-    bool queue_dry = false;                                    // wave-uniform: the global pixel queue has run out
-
-    uint32_t leaf_wait = 0;
-    for (;;) {
-        // ---------------- A. rays that finished in the last iteration: hit record out, slot into Q_shade -------------
-        {
-            const unsigned long long m_done = __ballot(lstate == L_DONE);
-            if (m_done != 0ull) {
-                if (lstate == L_DONE) {
-                    hit[0][pid] = best_t; hit[1][pid] = best_u; hit[2][pid] = best_v; hit[3][pid] = __uint_as_float(best_tri);
-                    qs[(qs_tail + lane_rank(m_done)) & (kPaths - 1u)] = pid;
-                    lstate = L_IDLE;
-                }
-                qs_tail += (uint32_t)__popcll(m_done);
-            }
-        }
-        // ---------------- B. idle lanes take the next ready rays (LDS) -------------------------------------------------
-        {
-            const unsigned long long m_idle = __ballot(lstate == L_IDLE);
-            const uint32_t avail = qr_tail - qr_head;
-            if (m_idle != 0ull && avail != 0u) {
-                const uint32_t want = (uint32_t)__popcll(m_idle), k = want < avail ? want : avail;
-                const uint32_t r = lane_rank(m_idle);
-                if (lstate == L_IDLE && r < k) {
-                    const uint32_t e = (qr_head + r) & 63u;
-                    o = mk(ring[0][e], ring[1][e], ring[2][e]);
-                    d = mk(ring[3][e], ring[4][e], ring[5][e]);
-                    rd = mk(ring[6][e], ring[7][e], ring[8][e]);
-                    safe_bits = __float_as_uint(ring[9][e]);
-                    pid = __float_as_uint(ring[10][e]);
-                    best_t = kMiss; best_u = 0.0f; best_v = 0.0f; best_tri = kNoTri;      // ray.rs:84-88, HitInfo::default
-                    sp = 0; pair = 0u;
-                    tri_cur = sc.root_a; tri_end = sc.root_a + sc.root_n;
-                    lstate = L_T;
-                }
-                qr_head += k;
-            }
-        }
-        const unsigned long long m_t = __ballot(lstate == L_T);
-        const uint32_t n_t = (uint32_t)__popcll(m_t), n_sh = qs_tail - qs_head;
-        // ---------------- C. service: a batch of up to 64 paths, one per lane ------------------------------------------
-        // Only when Q_ray is empty (its LDS is the pass's scratch): with every lane busy that is exactly when 64 paths wait in Q_shade.
-        // A partial batch only when lanes are idle with nothing ready (the end of the frame), and then by the 3/8 rule of the kernel above.
-        const bool partial_ok = MIPT_Q_TAIL_RULE ? (n_t == 0u || n_sh * pr.service_den >= (n_t + n_sh) * pr.service_num) : true;
-        if (qr_tail == qr_head && (n_sh >= 64u || (n_sh != 0u && n_t < 64u && partial_ok))) {
-            if (COUNT) { g_serv++; g_serv_lanes += n_sh < 64u ? n_sh : 64u; g_t0 = clock64(); }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t nb = n_sh < 64u ? n_sh : 64u;
-            const bool act = lane < nb;
-            uint32_t spid = 0, state = ST_X;
-            V3 so = mk(0, 0, 0), sd = mk(0, 0, 1);
-            V3 ray_color = mk(1, 1, 1), incoming = mk(0, 0, 0), emitted = mk(0, 0, 0), final_color = mk(0, 0, 0);
-            uint32_t rng = 0, pix = 0, slot = 0, sample = 0, bounces = 0;
-            float h_t = kMiss, h_u = 0, h_v = 0;
-            uint32_t h_tri = kNoTri;
-            if (act) {
-                spid = qs[(qs_head + lane) & (kPaths - 1u)];
-                const float4 v0 = rec_load(recs, rec_off(spid, 0u)), v1 = rec_load(recs, rec_off(spid, 1u)), v2 = rec_load(recs, rec_off(spid, 2u));
-                const float4 v4 = rec_load(recs, rec_off(spid, 4u)), v5 = rec_load(recs, rec_off(spid, 5u)), v6 = rec_load(recs, rec_off(spid, 6u)), v7 = rec_load(recs, rec_off(spid, 7u));
-                so = mk(v0.x, v0.y, v0.z); sd = mk(v1.x, v1.y, v1.z); sample = __float_as_uint(v1.w); bounces = __float_as_uint(v2.w);
-                h_t = hit[0][spid]; h_u = hit[1][spid]; h_v = hit[2][spid]; h_tri = __float_as_uint(hit[3][spid]);
-                ray_color = mk(v4.x, v4.y, v4.z); rng = __float_as_uint(v4.w);
-                incoming = mk(v5.x, v5.y, v5.z); pix = __float_as_uint(v5.w);
-                emitted = mk(v6.x, v6.y, v6.z); slot = __float_as_uint(v6.w);
-                final_color = mk(v7.x, v7.y, v7.z); state = __float_as_uint(v7.w);
-            }
-            qs_head += nb;
-
-            bool start_ray = false, scatter = false, path_done = false;
-            V3 sc_normal = mk(0, 0, 0);
-            if (state == ST_S) {
-                if (h_tri != kNoTri) {                                           // ray.rs:152-183
-                    const uint32_t tri = h_tri & ~kFrontBit;
-                    const float4 a0 = sc.tri_attr[(size_t)tri * 4 + 0], a1 = sc.tri_attr[(size_t)tri * 4 + 1];
-                    const float4 a2 = sc.tri_attr[(size_t)tri * 4 + 2], a3 = sc.tri_attr[(size_t)tri * 4 + 3];
-                    if (COUNT && pr.touched) mark_line(pr.touched, pr.touched_attr_base + (tri >> 1));
-                    const float u = h_u, v = h_v;
-                    const float w = 1.0f - u - v;                                   // ray.rs:45
-                    V3 normal = mk(a0.x, a0.y, a0.z) * w + mk(a0.w, a1.x, a1.y) * u + mk(a1.z, a1.w, a2.x) * v;
-                    if (!(h_tri & kFrontBit)) normal = mk(-normal.x, -normal.y, -normal.z); // ray.rs:46-48
-                    const float uvx = ((a2.y * w) + (a2.w * u)) + (a3.y * v);       // ray.rs:50-53
-                    const float uvy = ((a2.z * w) + (a3.x * u)) + (a3.z * v);
-                    const DevMaterial m = sc.mats[__float_as_uint(a3.w)];           // ray.rs:153-154
-                    if (m.base_w != 0u) {                                           // ray.rs:162-169
-                        ray_color = ray_color * texel_rgb(sc, m.base_off, m.base_w, m.base_h, uvx, uvy, pr.stats);
-                        if (COUNT) c_tex++;
-                    } else {
-                        ray_color = ray_color * mk(m.base[0], m.base[1], m.base[2]);
-                    }
-                    if (m.emis_w != 0u) {                                           // ray.rs:170-176
-                        emitted = emitted + texel_rgb(sc, m.emis_off, m.emis_w, m.emis_h, uvx, uvy, pr.stats);
-                        if (COUNT) c_tex++;
-                    } else {
-                        emitted = emitted + mk(m.emis[0], m.emis[1], m.emis[2]);
-                    }
-                    incoming = incoming + emitted * ray_color;                       // ray.rs:177
-                    scatter = true; sc_normal = normal;                              // ray.rs:179-183 below, wave-cooperatively
-                    if (COUNT) c_hits++;
-                } else {                                                             // ray.rs:184-193
-                    ray_color = ray_color * mk(1.0f, 1.0f, 1.0f);
-                    emitted = emitted + mk(1.0f, 1.0f, 1.0f);
-                    incoming = incoming + emitted * ray_color;
-                    path_done = true;
-                }
-            }
-            {   // Vec3f::rand_in_unit_sphere (vec3.rs:66-68) for every hit lane, evaluated by all 64 lanes (see the kernel above)
-                float *dr = &ring[0][0];
-                const unsigned long long m_sc = __ballot(scatter);
-                const uint32_t n_items = 3u * (uint32_t)__popcll(m_sc);
-                if (n_items != 0u) {
-                    const uint32_t base = 6u * lane_rank(m_sc);
-                    if (scatter) {
-#pragma unroll
-                        for (int k = 0; k < 6; k++) dr[base + k] = rand_f32(rng);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t item = lane; item < n_items; item += 64u) {
-                        const float2 uu = *reinterpret_cast<const float2 *>(dr + 2u * item);
-                        dr[2u * item] = rand_f32_nd_eval(uu.x, uu.y, (const double *)s_logtab);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (scatter) {
-                        const V3 rs = normalized(mk(dr[base], dr[base + 2u], dr[base + 4u]));
-                        const V3 point = so + sd * h_t;                              // ray.rs:60
-                        const V3 new_dir = normalized(sc_normal + rs);              // ray.rs:179-180
-                        so = point + new_dir * 0.0001f;                              // ray.rs:181
-                        sd = new_dir;
-                        bounces += 1;
-                        path_done = !(bounces < pr.max_depth);                       // ray.rs:147
-                    }
-                }
-            }
-            if (state == ST_S) {
-                if (path_done) {
-                    const V3 res = (bounces == 0u) ? incoming : incoming / (float)bounces; // ray.rs:197-201
-                    final_color = final_color + res;                                 // cpu.rs:52
-                    sample += 1;
-                    if (sample < pr.samples) {
-                        state = ST_G;
-                    } else {
-                        if (!pr.sum_only) final_color = final_color / pr.samples_f;  // cpu.rs:60
-                        float *dst = pr.hdr + (size_t)slot * 3;
-                        if (pr.accumulate) final_color = mk(dst[0] + final_color.x, dst[1] + final_color.y, dst[2] + final_color.z);
-                        dst[0] = final_color.x; dst[1] = final_color.y; dst[2] = final_color.z;
-                        c_pixels++;
-                        state = ST_P;
-                    }
-                } else {
-                    state = ST_T;
-                    start_ray = true;
-                }
-            }
-            {   // fetch a pixel: one atomic per batch
-                const unsigned long long m_p = __ballot(state == ST_P);
-                if (m_p != 0ull && !queue_dry) {
-                    unsigned long long base = 0;
-                    const uint32_t leader = (uint32_t)__ffsll((long long)m_p) - 1u;
-                    if (lane == leader) base = atomicAdd(&pr.stats->queue, (unsigned long long)__popcll(m_p));
-                    base = __shfl(base, (int)leader);
-                    if (state == ST_P) {
-                        const unsigned long long wi = base + lane_rank(m_p);
-                        if (wi >= pr.total_work) {
-                            state = ST_X;
-                            if (COUNT && g_t_first_x == 0) g_t_first_x = clock64();
-                        } else {
-                            const uint32_t lt = (uint32_t)(wi >> 6), p = (uint32_t)wi & 63u;
-                            const uint32_t lt_o = pr.reverse_tiles ? (pr.n_local_tiles - 1u - lt) : lt;
-                            const uint32_t gt = lt_o * pr.tile_world + pr.tile_rank;
-                            const uint32_t px = (gt % pr.tiles_x) * 8u + (p & 7u);
-                            const uint32_t py = (gt / pr.tiles_x) * 8u + (p >> 3);
-                            if (px < pr.width && py < pr.height) {            // ragged edge tiles: skip, ask again in a later batch
-                                pix = py * pr.width + px;
-                                slot = pr.packed ? (lt_o * 64u + p) : pix;
-                                rng = 987612486u * (pix + 87636354u);                 // cpu.rs:28-29
-                                final_color = mk(0.0f, 0.0f, 0.0f);
-                                sample = 0;
-                                state = ST_G;
-                            }
-                        }
-                    }
-                    queue_dry = (base + (unsigned long long)__popcll(m_p)) >= pr.total_work;
-                } else if (queue_dry && state == ST_P) {
-                    state = ST_X;
-                }
-            }
-            if (state == ST_G) {                                                      // camera ray (cpu.rs:31-50)
-                const uint32_t px = pix % pr.width, py = pix / pr.width;
-                if (pr.seed_mode != 0u) rng = (pr.sample_begin + sample) * 6023u + (757283u * px + 872653746u * py);   // rt_compute.wgsl:102
-                const uint32_t y = pr.height - py;                                    // cpu.rs:32
-                const float screen_x = ((((float)px / (float)pr.width) * 2.0f) - 1.0f) * pr.aspect; // cpu.rs:33-34
-                const float screen_y = (((float)y / (float)pr.height) * 2.0f) - 1.0f;               // cpu.rs:35
-                const float jx = (rand_f32(rng) * 2.0f - 1.0f) * 0.0005f;
-                const float jy = (rand_f32(rng) * 2.0f - 1.0f) * 0.0005f;
-                const float rx = -screen_x + jx, ry = screen_y + jy, rz = 1.0f;
-                const V3 dir = mk(pr.cam[0] * rx + pr.cam[3] * ry + pr.cam[6] * rz,
-                                  pr.cam[1] * rx + pr.cam[4] * ry + pr.cam[7] * rz,
-                                  pr.cam[2] * rx + pr.cam[5] * ry + pr.cam[8] * rz);
-                sd = normalized(dir);
-                so = mk(pr.cam[9], pr.cam[10], pr.cam[11]);
-                ray_color = mk(1.0f, 1.0f, 1.0f);                                     // ray.rs:142-146
-                incoming = mk(0.0f, 0.0f, 0.0f);
-                emitted = mk(0.0f, 0.0f, 0.0f);
-                bounces = 0;
-                state = ST_T;
-                start_ray = true;
-            }
-            // ---- out: paths with a new ray -> record + Q_ray; paths still without a pixel -> back into Q_shade; the rest is done ----
-            const bool to_ray = act && start_ray;
-            const bool retry = act && state == ST_P;
-            if (retry) rec_store(recs, rec_off(spid, 7u), make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_P)));
-            const unsigned long long m_r = __ballot(to_ray), m_b = __ballot(retry);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");            // the draws in the ring's memory have been read by every lane
-            __builtin_amdgcn_wave_barrier();
-            if (to_ray) {
-                const V3 srd = mk(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z);
-                const uint32_t safe = ray_safe(so, sd, sc.tiny_axes) ? 1u : 0u;
-                rec_store(recs, rec_off(spid, 0u), make_float4(so.x, so.y, so.z, __uint_as_float(safe)));
-                rec_store(recs, rec_off(spid, 1u), make_float4(sd.x, sd.y, sd.z, __uint_as_float(sample)));
-                rec_store(recs, rec_off(spid, 2u), make_float4(srd.x, srd.y, srd.z, __uint_as_float(bounces)));
-                rec_store(recs, rec_off(spid, 4u), make_float4(ray_color.x, ray_color.y, ray_color.z, __uint_as_float(rng)));
-                rec_store(recs, rec_off(spid, 5u), make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(pix)));
-                rec_store(recs, rec_off(spid, 6u), make_float4(emitted.x, emitted.y, emitted.z, __uint_as_float(slot)));
-                rec_store(recs, rec_off(spid, 7u), make_float4(final_color.x, final_color.y, final_color.z, __uint_as_float((uint32_t)ST_S)));
-                const uint32_t e = (qr_tail + lane_rank(m_r)) & 63u;
-                ring[0][e] = so.x; ring[1][e] = so.y; ring[2][e] = so.z;
-                ring[3][e] = sd.x; ring[4][e] = sd.y; ring[5][e] = sd.z;
-                ring[6][e] = srd.x; ring[7][e] = srd.y; ring[8][e] = srd.z;
-                ring[9][e] = __uint_as_float(safe); ring[10][e] = __uint_as_float(spid);
-                if (COUNT) c_rays++;
-            }
-            if (retry) qs[(qs_tail + lane_rank(m_b)) & (kPaths - 1u)] = spid;
-            qr_tail += (uint32_t)__popcll(m_r);
-            qs_tail += (uint32_t)__popcll(m_b);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // the rays the lanes are in the middle of were not kept in registers across the pass (its f64 arithmetic needs them):
-            // every lane re-reads o, d, 1/d of its path slot -- unconditionally, so that the old values are dead above
-            {
-                const float4 v0 = rec_load(recs, rec_off(pid, 0u)), v1 = rec_load(recs, rec_off(pid, 1u)), v2 = rec_load(recs, rec_off(pid, 2u));
-                o = mk(v0.x, v0.y, v0.z); safe_bits = __float_as_uint(v0.w);
-                d = mk(v1.x, v1.y, v1.z); rd = mk(v2.x, v2.y, v2.z);
-                // wait for them HERE: with loads into o / d / rd still in flight at the loop head, step B (which overwrites the same
-                // registers from LDS) gets a static vmcnt(0) in front of it, which would also catch step A's store in every iteration
-                asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(d.x), "v"(d.y), "v"(d.z), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(safe_bits));
-            }
-            if (COUNT) g_t_serv += clock64() - g_t0;
-            continue;
-        }
-        if (n_t == 0u) break;        // nothing traversing, nothing to shade, nothing ready: every path of this wave is done
-
-        // ---------------- D. one traversal step per traversing lane (identical to the kernel above) -------------------
-        bool leaf_hold;
-        {
-            const unsigned long long m_lf = __ballot(lstate == L_T && tri_cur < tri_end);
-            const unsigned long long m_in = __ballot(lstate == L_T && !(tri_cur < tri_end));
-            const bool phase = leaf_wait == 0u || m_in == 0ull || (uint32_t)__popcll(m_lf) * pr.leaf_den >= n_t;
-            leaf_wait = phase ? pr.leaf_period - 1u : leaf_wait - 1u;
-            leaf_hold = !phase;
-            if (COUNT) {
-                g_iters++;
-                g_inner += (unsigned long long)__popcll(m_in); g_it_inner += (m_in != 0ull) ? 1u : 0u;
-                g_leaf += phase ? (unsigned long long)__popcll(m_lf) : 0ull; g_it_leaf += (phase && m_lf != 0ull) ? 1u : 0u;
-            }
-        }
-        if (lstate == L_T && !(leaf_hold && tri_cur < tri_end)) {
-            const bool leaf = tri_cur < tri_end;
-            const uint32_t voff = leaf ? (sc.tri_off_bytes + tri_cur * kTriPosStride) : (pair * 64u);
-            const uint32_t top_e = stk[(sp - 1u) & (uint32_t)(kStackLds - 1)][lane];
-            float4 r0, r1, r2, r3;
-            r0 = ldg4(geom, voff); r1 = ldg4(geom, voff + 16u); r2 = ldg4(geom, voff + 32u);
-            r3 = ldg4(geom, voff + 48u);
-            if (COUNT && pr.touched) mark_line(pr.touched, voff >> 7);
-            asm volatile("" ::: "memory");
-            bool need_pop = false;
-            if (leaf) {                                                              // ray.rs:19-67, 90-99
-                const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-                const V3 rce2 = cross(d, e2);
-                const float det = dot(e1, rce2);
-                const float inv_det = 1.0f / det;
-                const V3 s = o - v0;
-                const float u = inv_det * dot(s, rce2);
-                const V3 sce1 = cross(s, e1);
-                const float v = inv_det * dot(d, sce1);
-                const float t = inv_det * dot(e2, sce1);
-                const bool has_hit = (t > 0.0f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
-                if (has_hit && t < best_t) {                                         // ray.rs:96 (strict <)
-                    best_t = t; best_u = u; best_v = v;
-                    best_tri = __float_as_uint(r2.y) | ((det > 0.0f) ? kFrontBit : 0u);
-                }
-                if (COUNT) c_tris++;
-                tri_cur += 1;
-                need_pop = (tri_cur == tri_end);
-            } else {                                                                 // ray.rs:108-137
-                const float max_d = best_t * pr.cull_scale;
-                float d1, d2;
-                slab_pair<CULL>(o, d, rd, safe_bits != 0u, r0, r1, r2, r3, max_d, d1, d2);
-                uint32_t a1 = __float_as_uint(r0.w), n1 = __float_as_uint(r1.w);
-                uint32_t a2 = __float_as_uint(r2.w), n2 = __float_as_uint(r3.w);
-                uint32_t w2 = 1u;
-                if (COUNT) c_inner++;
-                if (d1 > d2) {                                                       // ray.rs:120-123
-                    float td = d1; d1 = d2; d2 = td;
-                    uint32_t ta = a1; a1 = a2; a2 = ta;
-                    uint32_t tn = n1; n1 = n2; n2 = tn;
-                    w2 = 0u;
-                }
-                if (d1 == kMiss) {                                                   // ray.rs:124-130
-                    need_pop = true;
-                } else {
-                    const bool push = d2 < kMiss;                                    // ray.rs:133-136
-                    const uint32_t e = encode_child(a2, n2, pair, w2);
-                    const bool in_lds = sp < (uint32_t)kStackLds;
-                    stk[(push && in_lds) ? sp : (uint32_t)kStackLds][lane] = e;
-                    if (push && !in_lds) {
-                        if (sp < (uint32_t)(kStackLds + kStackOvf)) ovf[(size_t)(sp - kStackLds) * 64] = e;
-                        else atomicAdd(&pr.stats->stack_overflows, 1ull);
-                    }
-                    sp += (push && sp < (uint32_t)(kStackLds + kStackOvf)) ? 1u : 0u;
-                    if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
-                    if (n1 > 0u) { tri_cur = a1; tri_end = a1 + n1; }
-                    else { pair = a1; }
-                }
-            }
-            if (need_pop) {                                                          // ray.rs:100-105, 125-129
-                if (sp == 0u) {
-                    lstate = L_DONE;                                                 // traverse_bvh returns: step A of the next iteration
-                } else {
-                    sp -= 1;
-                    uint32_t e = top_e;
-                    if (sp >= (uint32_t)kStackLds) e = ovf[(size_t)(sp - kStackLds) * 64];
-                    if (e & 0x80000000u) {
-                        uint32_t n = (e >> 25) & 63u, a = e & 0x01ffffffu;
-                        if (n == 0u) {
-                            const uint32_t ref = e & 0x7fffffffu;
-                            const float4 *q = sc.pairs + (size_t)(ref >> 1) * 4 + (ref & 1u) * 2;
-                            a = __float_as_uint(q[0].w); n = __float_as_uint(q[1].w);
-                        }
-                        tri_cur = a; tri_end = a + n;
-                    } else {
-                        pair = e; tri_cur = 0; tri_end = 0;
-                    }
-                }
-            }
-        }
-    }
-
-    if (COUNT) {
-        atomicAdd(&pr.stats->rays, c_rays);
-        atomicAdd(&pr.stats->inner_steps, c_inner);
-        atomicAdd(&pr.stats->tri_tests, c_tris);
-        atomicAdd(&pr.stats->hits, c_hits);
-        atomicAdd(&pr.stats->texel_fetches, c_tex);
-        atomicMax(&pr.stats->max_stack, (unsigned long long)c_maxsp);
-        if (lane == 0) {
-            atomicAdd(&pr.stats->d_iters, g_iters); atomicAdd(&pr.stats->d_inner_lanes, g_inner);
-            atomicAdd(&pr.stats->d_leaf_lanes, g_leaf); atomicAdd(&pr.stats->d_iters_inner, g_it_inner);
-            atomicAdd(&pr.stats->d_iters_leaf, g_it_leaf); atomicAdd(&pr.stats->d_services, g_serv);
-            atomicAdd(&pr.stats->d_service_lanes, g_serv_lanes);
-            atomicAdd(&pr.stats->d_cycles_service, g_t_serv);
-            atomicAdd(&pr.stats->d_cycles_total, clock64() - g_t_start);
-        }
-        {
-            const unsigned long long tx = __shfl(g_t_first_x, (int)(__ffsll((long long)__ballot(g_t_first_x != 0)) - 1));
-            if (lane == 0 && tx != 0) atomicAdd(&pr.stats->d_cycles_tail, clock64() - tx);
-        }
-    }
-    if (c_pixels) atomicAdd(&pr.stats->pixels, (unsigned long long)c_pixels);
-}
-
 // ---- all-gathered rank-packed tile slices -> full frame -----------------------------------
 __global__ void unpack_tiles_kernel(const float *__restrict__ packed_all, uint32_t width, uint32_t height,
                                     uint32_t world, uint32_t tiles_x, uint32_t n_local_tiles, float *__restrict__ hdr) {
@@ -1250,38 +787,23 @@ static int occ_t() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel<COUNT, CULL, SHADING>, kBlockThreads, 0) != hipSuccess) n = 1;
     return n;
 }
-template <bool COUNT, bool CULL>
-static hipError_t launch_q(const DevScene &sc, const DevParams &pr, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL((pt_trace_kernel_q<COUNT, CULL>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, pr);
-    return hipGetLastError();
-}
-template <bool COUNT, bool CULL>
-static int occ_q() {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_trace_kernel_q<COUNT, CULL>, kBlockThreads, 0) != hipSuccess) n = 1;
-    return n;
-}
-// instantiations: {CPU-backend shading, wgpu-shader shading} x {count, cull}; CPU-backend shading also as the queue variant
-#define MIPT_DISPATCH(FN, FNQ, ...)                                                                                     \
+// instantiations: {CPU-backend shading, wgpu-shader shading} x {count, cull}
+#define MIPT_DISPATCH(FN, ...)                                                                                          \
     do {                                                                                                                \
         if (shading == 1) {                                                                                             \
             if (count) return cull ? FN<true, true, 1>(__VA_ARGS__) : FN<true, false, 1>(__VA_ARGS__);                  \
             return cull ? FN<false, true, 1>(__VA_ARGS__) : FN<false, false, 1>(__VA_ARGS__);                           \
         }                                                                                                               \
-        if (queue) {                                                                                                    \
-            if (count) return cull ? FNQ<true, true>(__VA_ARGS__) : FNQ<true, false>(__VA_ARGS__);                      \
-            return cull ? FNQ<false, true>(__VA_ARGS__) : FNQ<false, false>(__VA_ARGS__);                               \
-        }                                                                                                               \
         if (count) return cull ? FN<true, true, 0>(__VA_ARGS__) : FN<true, false, 0>(__VA_ARGS__);                      \
         return cull ? FN<false, true, 0>(__VA_ARGS__) : FN<false, false, 0>(__VA_ARGS__);                               \
     } while (0)
 
-hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int shading, bool queue, int grid, hipStream_t stream) {
-    MIPT_DISPATCH(launch_t, launch_q, sc, pr, grid, stream);
+hipError_t launch_trace(const DevScene &sc, const DevParams &pr, bool count, bool cull, int shading, int grid, hipStream_t stream) {
+    MIPT_DISPATCH(launch_t, sc, pr, grid, stream);
 }
-static int occ_dispatch(bool count, bool cull, int shading, bool queue) { MIPT_DISPATCH(occ_t, occ_q); }
-int trace_blocks_per_cu(bool count, bool cull, int shading, bool queue) {
-    int n = occ_dispatch(count, cull, shading, queue);
+static int occ_dispatch(bool count, bool cull, int shading) { MIPT_DISPATCH(occ_t); }
+int trace_blocks_per_cu(bool count, bool cull, int shading) {
+    int n = occ_dispatch(count, cull, shading);
     if (n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
