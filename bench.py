@@ -116,18 +116,21 @@ def baseline_metric():
         return "Mray/s at 1920x1080, 8 spp, Sponza BVH; 1/2/4/8-GPU scaling + % HBM roofline"
 
 
-def physical_cores() -> int:
+def cpu_quota_cores():
+    """CPU time this process may use, in cores, from the cgroup (v2 cpu.max, v1 cfs quota); None = unlimited.  A GPU box of the pool
+    shows all 256 hardware threads of its host but grants a 1-GPU lease 16 cores' worth of time: 256 runnable threads are then
+    throttled to 1/16 each (round 2's 13 kray/s per thread -- ~1 us per node visit -- was that, not memory placement)."""
     try:
-        seen = set()
-        base = "/sys/devices/system/cpu"
-        for d in os.listdir(base):
-            if d.startswith("cpu") and d[3:].isdigit():
-                p = os.path.join(base, d, "topology", "thread_siblings_list")
-                if os.path.exists(p):
-                    seen.add(open(p).read().strip())
-        return len(seen) or (os.cpu_count() or 1)
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
     except Exception:
-        return os.cpu_count() or 1
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
 
 
 def log(rank, *a):
@@ -486,7 +489,11 @@ def main():
         mats_arr = scene.materials_array()
         seed_mode = 0 if mode == "tiles" else 1
 
-        def cpu(stride, threads=0, spread=0):
+        hw_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = cpu_quota_cores()
+        n_thr = max(1, min(hw_threads, int(np.ceil(quota)))) if quota else hw_threads     # one thread per core the cgroup grants
+
+        def cpu(stride, threads=n_thr, spread=0):
             return orc.render(scene.tris, scene.bvh_nodes, mats_arr, scene.textures, scene.camera.uniform, w, h, spp, depth,
                               cull=0, pix_stride=stride, want_rgba8=False, threads=threads, seed_mode=seed_mode, spread_pages=spread)
         _, _, ps = cpu(8191)
@@ -501,11 +508,13 @@ def main():
                     "seconds": round(s["seconds"], 2), "uniform_blocks": s["n_blocks"],
                     "slowest_block_over_mean_block": round(s["block_sec_max"] / max(s["block_sec_mean"], 1e-9), 3)}
         head = summary(cs)
-        phys = physical_cores()
         result["cpu_baseline"] = {"value": head["value"], "unit": "Mray/s", "cores": cs["threads_used"], "kind": "port",
                                   "sample": f"every {stride}th pixel of the same frame ({cs['rays']} rays, {cs['seconds']:.1f} s), "
                                             "C restatement of the reference's rayon backend (no t-max cull), all samples and bounces, "
                                             "uniform contiguous pixel blocks as cpu.rs:22-26",
+                                  "host": {"hardware_threads_visible": hw_threads, "cgroup_cpu_quota_cores": quota,
+                                           "note": "threads = the cores the cgroup grants this process (cpu.max); rayon would start one thread per "
+                                                   "visible hardware thread and be throttled to the same total"},
                                   "memory_placement": "reference-faithful: the scene arrays are allocated and filled by ONE thread (the reference builds its "
                                                       "Vecs on the main thread, scene.rs:44-85), so on a multi-socket host every page sits on one NUMA node; "
                                                       "numa_spread_run is the same sample with the pages first-touched share by share by the worker threads",
@@ -513,9 +522,9 @@ def main():
                                   "slowest_block_over_mean_block": head["slowest_block_over_mean_block"]}
         _, _, cn = cpu(stride, spread=1)
         result["cpu_baseline"]["numa_spread_run"] = summary(cn)
-        if phys and phys != cs["threads_used"]:
-            _, _, cp = cpu(stride, threads=phys)
-            result["cpu_baseline"]["physical_cores_run"] = summary(cp)
+        if n_thr != hw_threads:
+            _, _, cp = cpu(stride, threads=hw_threads)
+            result["cpu_baseline"]["all_hardware_threads_run"] = summary(cp)       # what a rayon pool sized by available_parallelism would do here
         if not args.no_parity:
             got = frame_primary.cpu().numpy().reshape(h, w, 3)
             idx = np.arange(0, n_pix, stride)
