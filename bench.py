@@ -107,6 +107,19 @@ def pmc_traffic(n_tris_requested, w, h, spp, depth, traversal, mode):
     return None, why
 
 
+def step_roof():
+    """G lane-steps/s a traversal-shaped chain reaches on this chip with the product's cache-hit mix and occupancy (all lanes busy, the
+    product's slab arithmetic included): tools/calib/step_roof.hip -> profiles/r3_step_roof.jsonl.  None if the file is missing."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r3_step_roof.jsonl")):
+            d = json.loads(line)
+            if d["variant"].startswith("gather_slab (hit mix, 64 lanes)"):
+                return float(d["G_lane_steps_s"])
+    except Exception:
+        pass
+    return None
+
+
 def baseline_metric():
     """The metric string of BASELINE.json (the file travels with the repo); the literal is its value at the time of writing."""
     try:
@@ -374,6 +387,8 @@ def main():
     alg_bytes = algorithmic_bytes(local_counts, n_local_samples)
     dev_bytes = device_bytes(local_counts, local_counts["pixels"])
     achieved = alg_bytes / avg_kernel_s / 1e9
+    lane_steps = local_counts["inner_steps"] + local_counts["tri_tests"]
+    roof = step_roof() if (args.tris, w, h) == (10_000_000, 1920, 1080) and mode == "tiles" and args.traversal == "culled" else None
     unique_bytes = (sum(local_counts["touched_lines"]) * 128 + 12 * local_counts["pixels"]) if sum(local_counts["touched_lines"]) else None
     traffic, prov = pmc_traffic(args.tris, w, h, spp, depth, args.traversal, mode) if world == 1 else (None, "N > 1")
     seeds = "pixel-stream seeds (cpu.rs:28-29)" if mode == "tiles" else "per-sample seeds (rt_compute.wgsl:102)"
@@ -416,7 +431,13 @@ def main():
                      "kernel": "pt_trace_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3), "kernel_source_sha": kernel_source_sha(),
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": round(alg_bytes / max(local_counts["rays"], 1), 1),
                      "device_bytes_per_launch": dev_bytes, "device_GBs": round(dev_bytes / avg_kernel_s / 1e9, 1),
-                     "mray_s_kernel": round(local_counts["rays"] / avg_kernel_s / 1e6, 2)},
+                     "mray_s_kernel": round(local_counts["rays"] / avg_kernel_s / 1e6, 2),
+                     # a roof in the kernel's own unit: one lane-step = one 64-B record gathered at an address that depends on the last one
+                     "step_roof": ({"unit": "G lane-steps/s", "achieved": round(lane_steps / avg_kernel_s / 1e9, 1), "peak": roof,
+                                    "frac": round(lane_steps / avg_kernel_s / 1e9 / roof, 3),
+                                    "basis": "peak = a dependent 4 x 16-B gather chain + the product's slab arithmetic, every lane busy, same occupancy, "
+                                             "the product's measured L1 / L2 / memory-side hit mix (tools/calib/step_roof.hip, profiles/r3_step_roof.jsonl); "
+                                             "achieved = (inner steps + triangle tests) / kernel time"} if roof else None)},
     }
     if single:
         result["single_process"] = {
