@@ -269,7 +269,7 @@ extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nod
 // ---- order of the device's 64-B pair records (pair k = {nodes[2k+1], nodes[2k+2]}; mipt_api.cpp builds the records) ----
 // The memory side moves whole 128-B lines and a traversal step gathers ONE 64-B record, so what matters is which record shares a
 // record's line.  Two zones:
-//   * the top kPairLayoutTop levels, which every ray walks through and which stay resident in L1 / L2: breadth-first, level after
+//   * the top MIPT_PAIR_LAYOUT_TOP levels, which every ray walks through and which stay resident in L1 / L2: breadth-first, level after
 //     level, every level starting on a line boundary -- one dense run of lines;
 //   * below them, where a line is cold whenever a ray reaches it: a pair shares its line with the child pair of its LARGER inner
 //     child (half area: SAH's own proxy for "the child the ray enters").  The step after a cold pair is then a hit more often than
@@ -311,9 +311,9 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         };
         uint32_t depth = 0;
         while (!level.empty()) {
-            if (order.size() + 2 * level.size() + 2 > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;
             couples.clear(); singles.clear();
             if (depth < (uint32_t)MIPT_PAIR_LAYOUT_TOP) {
+                if (order.size() + level.size() + 1 > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;   // also bounds a malformed (shared-child) input
                 if (order.size() & 1u) order.push_back(0xffffffffu);
                 for (uint32_t k : level) order.push_back(k);
             } else {
@@ -324,10 +324,13 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
                     if (!ha && !hb) { lone.push_back(k); continue; }
                     uint32_t pick = ha ? ca : cb;
                     if (ha && hb && half_area(2 * k + 2) > half_area(2 * k + 1)) pick = cb;
+                    if (taken[pick]) return MIPT_ERR_BVH;                            // a child pair with two parents: not a tree
+                    if (order.size() + 3 > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;
                     if (order.size() & 1u) order.push_back(0xffffffffu);
                     order.push_back(k); order.push_back(pick);
                     taken[pick] = 1;
                 }
+                if (lone.size() > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;
             }
             for (uint32_t k : level) {
                 uint32_t ca = 0, cb = 0;
