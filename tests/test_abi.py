@@ -127,3 +127,46 @@ def test_fails_loudly_without_a_device(rrt):
     import pytest
     with pytest.raises(rrt.MiptError):
         r.render_buffers(sc)
+
+
+def test_scene_create_survives_random_bvh_garbage(rrt):
+    """Fuzz of the upload-time validation (no GPU needed: it runs before any device work).  Random node arrays -- child indices,
+    triangle ranges and leaf sizes drawn at random, and mutations of a valid tree -- must come back with a status code quickly:
+    MIPT_ERR_BVH / INVALID_ARG / SCENE_LIMIT for malformed input, MIPT_ERR_HIP (CPU box) or MIPT_OK (GPU box) for the few that happen
+    to be well-formed.  Never a crash, a hang or an unbounded allocation (a 55-node DAG once took 4 s and 1.2 GB)."""
+    import time
+    from rust_ray_tracing_amd import NODE, TRIANGLE, material_default
+    from rust_ray_tracing_amd import _lib as L
+    from rust_ray_tracing_amd import synth
+    lib = rrt.load()
+    rng = np.random.default_rng(1234)
+    mats = np.array([material_default()])
+    base = rrt.Scene.from_arrays(synth.make_scene("atrium", n_target=2000, tex_size=8)[0], [material_default()])
+    seen = set()
+    t0 = time.time()
+    for trial in range(400):
+        if trial % 2 == 0:                                   # pure garbage
+            n_nodes = int(rng.integers(1, 60)) | 1
+            n_tris = int(rng.integers(1, 40))
+            nodes = np.zeros(n_nodes, dtype=NODE)
+            nodes["bounds_max"] = 1.0
+            nodes["first_tri_or_child"] = rng.integers(0, 2 * n_nodes, n_nodes)
+            nodes["num_tris"] = np.where(rng.random(n_nodes) < 0.5, 0, rng.integers(0, 5, n_nodes))
+            tris = np.zeros(n_tris, dtype=TRIANGLE)
+        else:                                                # a valid tree with a few fields damaged
+            nodes = base.bvh_nodes.copy()
+            tris = base.tris
+            for _ in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(0, len(nodes)))
+                f = ("first_tri_or_child", "num_tris")[int(rng.integers(0, 2))]
+                nodes[i][f] = int(rng.integers(0, 2 * len(nodes)))
+        h = C.c_void_p()
+        d = L.MiptSceneDesc(L.ptr(tris), len(tris), L.ptr(nodes), len(nodes), L.ptr(mats), 1, None, 0)
+        rc = lib.mipt_scene_create(C.byref(d), 0, C.byref(h))
+        assert rc in (L.OK, L.ERR_HIP, L.ERR_BVH, L.ERR_INVALID_ARG, L.ERR_SCENE_LIMIT), rc
+        seen.add(rc)
+        if rc == L.OK:
+            lib.mipt_scene_destroy(h)
+        else:
+            assert h.value is None and len(lib.mipt_last_error()) > 0
+    assert L.ERR_BVH in seen and time.time() - t0 < 20.0
