@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind,kw,n_views,box,seed", [
-    ("atrium", dict(n_target=300000, tex_size=128), 6, 14.0, 11),
-    ("dragon", dict(n_target=200000), 4, 6.0, 12),
-    ("helmet", dict(n_target=15000, tex_size=64), 3, 4.0, 13),
+    ("atrium", dict(n_target=300000, tex_size=128), 9, 14.0, 11),
+    ("dragon", dict(n_target=200000), 6, 6.0, 12),
+    ("helmet", dict(n_target=15000, tex_size=64), 5, 4.0, 13),
+    ("cornell", {}, 4, 0.8, 14),
 ])
 def test_random_views_culled_equals_reference_equals_oracle(rrt, orc, kind, kw, n_views, box, seed):
     from rust_ray_tracing_amd import _lib as L
