@@ -32,17 +32,22 @@ void mipt_internal_set_error(const char *msg);
 namespace {
 
 constexpr int kT = 256;
+#ifndef MIPT_BVH_BLOCK_SPLIT
+#define MIPT_BVH_BLOCK_SPLIT 4096
+#endif
+constexpr uint32_t kBlockSplit = MIPT_BVH_BLOCK_SPLIT;   // block-class nodes above this many triangles get 1024 threads (build_level)
+
 constexpr float F32_MAX = FLT_MAX;
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kSubFlag = 0x80000000u;   // BNode::left = kSubFlag | pool index: the node's whole subtree lives in the pool (build_subtree_tiny)
 #ifndef MIPT_BVH_BIG
-#define MIPT_BVH_BIG 32768
+#define MIPT_BVH_BIG 8192
 #endif
 #ifndef MIPT_BVH_CHUNK
 #define MIPT_BVH_CHUNK 8192
 #endif
 #ifndef MIPT_BVH_WAVEMAX
-#define MIPT_BVH_WAVEMAX 512
+#define MIPT_BVH_WAVEMAX 2048
 #endif
 constexpr uint32_t kBig = MIPT_BVH_BIG;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
 constexpr uint32_t kChunk = MIPT_BVH_CHUNK;
@@ -53,7 +58,8 @@ constexpr uint32_t kWaveMax = MIPT_BVH_WAVEMAX;          // 17..kWaveMax triangl
 enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3, CLS_SUB = 4 };
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
 // children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
-struct Ctrl { uint32_t n_nodes; uint32_t n_chunks; uint32_t cnt[2][5]; uint32_t pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
+struct alignas(128) Pad32 { uint32_t v; uint32_t pad[31]; };        // one counter per 128-B line: atomics on one line serialise, whichever word they hit
+struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][5], pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
 struct Lists { uint32_t *l[2][5]; };
 
 struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
@@ -87,24 +93,30 @@ __device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint
     const unsigned long long active = __ballot(true);
     const int leader = (int)__ffsll((long long)active) - 1;
     const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long ma[5], mb[5];
+    uint32_t slot0[5];
+#pragma unroll
+    for (uint32_t c = 0; c < 5u; c++) { ma[c] = __ballot(ca == c); mb[c] = __ballot(cb == c); }
+#pragma unroll
+    for (uint32_t c = 0; c < 5u; c++) {                              // all the wave's list atomics in flight together: one round trip, not one per class
+        const uint32_t tot = (uint32_t)__popcll(ma[c]) + (uint32_t)__popcll(mb[c]);
+        slot0[c] = 0;
+        if (tot != 0u && (int)lane == leader) slot0[c] = atomicAdd(&ctrl->cnt[parity][c].v, tot);
+    }
 #pragma unroll
     for (uint32_t c = 0; c < 5u; c++) {
-        const unsigned long long ma = __ballot(ca == c), mb = __ballot(cb == c);
-        const uint32_t tot = (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
-        if (tot == 0u) continue;
-        uint32_t slot0 = 0;
-        if ((int)lane == leader) slot0 = atomicAdd(&ctrl->cnt[parity][c], tot);
-        slot0 = __shfl(slot0, leader);
+        if ((ma[c] | mb[c]) == 0ull) continue;
+        const uint32_t s0 = __shfl(slot0[c], leader);
         uint32_t *list = ls.l[parity][c];
-        if (ca == c) list[slot0 + mask_rank(ma)] = base_idx;
-        if (cb == c) list[slot0 + (uint32_t)__popcll(ma) + mask_rank(mb)] = base_idx + 1u;
+        if (ca == c) list[s0 + mask_rank(ma[c])] = base_idx;
+        if (cb == c) list[s0 + (uint32_t)__popcll(ma[c]) + mask_rank(mb[c])] = base_idx + 1u;
     }
 }
 struct Box3 { float lx, ly, lz, hx, hy, hz; };      // passed by value: keeps the callers' boxes in registers (pointer parameters made
                                                     // the one-thread-per-node kernel's locals spill into 40 KB of LDS per workgroup)
 __device__ __forceinline__ void emit_children(BNode *bn, Ctrl *ctrl, const Lists &ls, uint32_t next_parity, uint32_t node_i,
                                               Box3 A, Box3 B, uint32_t first, uint32_t k, uint32_t n) {
-    const uint32_t base = atomicAdd(&ctrl->n_nodes, 2u);
+    const uint32_t base = atomicAdd(&ctrl->n_nodes.v, 2u);
     BNode a, b;
     a.lo[0] = A.lx; a.lo[1] = A.ly; a.lo[2] = A.lz; a.hi[0] = A.hx; a.hi[1] = A.hy; a.hi[2] = A.hz;
     b.lo[0] = B.lx; b.lo[1] = B.ly; b.lo[2] = B.lz; b.hi[0] = B.hx; b.hi[1] = B.hy; b.hi[2] = B.hz;
@@ -116,6 +128,7 @@ __device__ __forceinline__ void emit_children(BNode *bn, Ctrl *ctrl, const Lists
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total = block sum
+template <int NW = 4>
 __device__ uint32_t block_exscan(uint32_t v, uint32_t *s_warp, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     uint32_t x = v;
@@ -124,7 +137,7 @@ __device__ uint32_t block_exscan(uint32_t v, uint32_t *s_warp, uint32_t *total) 
     if (lane == 63u) s_warp[w] = x;
     __syncthreads();
     uint32_t add = 0, tot = 0;
-    for (uint32_t i = 0; i < 4u; i++) { const uint32_t sw = s_warp[i]; if (i < w) add += sw; tot += sw; }
+    for (uint32_t i = 0; i < (uint32_t)NW; i++) { const uint32_t sw = s_warp[i]; if (i < w) add += sw; tot += sw; }
     __syncthreads();
     *total = tot;
     return add + x - v;
@@ -156,8 +169,12 @@ __global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
     bn[0] = r;
 }
 
-// one workgroup per node of this level's CLS_BLOCK list
-__global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__restrict__ list, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+// one workgroup per node of this level's CLS_BLOCK list.  A level lasts as long as its largest node (a 32 k-triangle node is 128
+// trips through each of the eight loops below for 256 threads: ~2 ms), while most block-class nodes have ~1 k triangles and want
+// many small workgroups: so two instantiations walk the same list on two streams -- kTB = 1024 threads for nodes above kBlockSplit
+// triangles, 256 for the rest -- and a workgroup whose node belongs to the other one leaves at once.
+template <int kTB>
+__global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__restrict__ list, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
                                                   uint32_t *hole_pos, uint32_t *tail_pos, Ctrl *ctrl, Lists ls, uint32_t next_parity) {
     // per axis, per bin: lo.xyz (min keys), hi.xyz (max keys) and the count.  kCopies private copies (thread & 7 picks one,
     // merged after the pass): with one copy the 64 lanes of a wave pile onto 8 addresses per atomic and serialise.
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     uint32_t(*s_cnt)[8] = s_cntc[0];
     __shared__ uint32_t s_cmin[3], s_cmax[3];
     __shared__ uint32_t s_ckey[2][6];        // child boxes (L, R)
-    __shared__ uint32_t s_warp[4];
+    __shared__ uint32_t s_warp[kTB / 64];
     __shared__ float s_pos[3][8];
     __shared__ int s_use[3];
     __shared__ int s_split, s_axis;
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     __shared__ uint32_t s_k;
 
     const uint32_t node_i = list[blockIdx.x];
+    if ((bn[node_i].n > kBlockSplit) != (kTB > 256)) return;          // uniform over the workgroup
     const BNode nd = bn[node_i];
     const uint32_t first = nd.first, n = nd.n, tid = threadIdx.x;
     const Proxy *in = pin + first;
@@ -182,13 +200,13 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
 
     // ---- 1. centroid ranges (bvh.rs:67-77; f32::MIN == -f32::MAX) ----
     if (tid < 3) { s_cmin[tid] = 0xffffffffu; s_cmax[tid] = 0u; }
-    for (uint32_t i = tid; i < kCopies * 144u; i += kT) (&s_keyc[0][0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
-    for (uint32_t i = tid; i < kCopies * 24u; i += kT) (&s_cntc[0][0][0])[i] = 0u;
+    for (uint32_t i = tid; i < kCopies * 144u; i += kTB) (&s_keyc[0][0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+    for (uint32_t i = tid; i < kCopies * 24u; i += kTB) (&s_cntc[0][0][0])[i] = 0u;
     if (tid < 12) (&s_ckey[0][0])[tid] = ((tid % 6) < 3) ? 0xffffffffu : 0u;
     __syncthreads();
     {
         float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-        for (uint32_t i = tid; i < n; i += kT)
+        for (uint32_t i = tid; i < n; i += kTB)
             for (int a = 0; a < 3; a++) { const float c = in[i].c[a]; mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c); }
         for (int a = 0; a < 3; a++) { atomicMin(&s_cmin[a], fkey(mn[a])); atomicMax(&s_cmax[a], fkey(mx[a])); }
     }
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     }
     __syncthreads();
     // ---- 2. binning: bin = first plane i (1..7) with c < pos_i, else 8 (stored at i-1) ----
-    for (uint32_t i = tid; i < n; i += kT) {
+    for (uint32_t i = tid; i < n; i += kTB) {
         const Proxy p = in[i];
         for (int a = 0; a < 3; a++) {
             if (!s_use[a]) continue;
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     }
     __syncthreads();
     if (!s_split) {                                   // leaf: carry the range over unchanged
-        for (uint32_t i = tid; i < n; i += kT) out[i] = in[i];
+        for (uint32_t i = tid; i < n; i += kTB) out[i] = in[i];
         return;
     }
     const int axis = s_axis;
@@ -266,9 +284,9 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     if (s_k == kNone) {                                 // only when no candidate was finite (NaN parent cost): count directly
         __syncthreads();
         uint32_t cnt = 0;
-        for (uint32_t i = tid; i < n; i += kT) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
+        for (uint32_t i = tid; i < n; i += kTB) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
         uint32_t tot;
-        (void)block_exscan(cnt, s_warp, &tot);
+        (void)block_exscan<kTB / 64>(cnt, s_warp, &tot);
         if (tid == 0) s_k = tot;
         __syncthreads();
     }
@@ -276,22 +294,22 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     uint32_t *hp = hole_pos + first, *tp = tail_pos + first;
     // holes: positions p < k holding ">=", in increasing p  ->  hp[m] = p
     uint32_t n_holes = 0;
-    for (uint32_t base = 0; base < k; base += kT) {
+    for (uint32_t base = 0; base < k; base += kTB) {
         const uint32_t p = base + tid;
         const uint32_t f = (p < k && !(in[p].c[axis] < pos)) ? 1u : 0u;
         uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
+        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (f) hp[n_holes + r] = p;
         n_holes += tot;
     }
     // tail "<": positions p >= k holding "<", in decreasing p  ->  tp[m] = p
     uint32_t n_tail = 0;
-    for (uint32_t base = 0; base < n - k; base += kT) {
+    for (uint32_t base = 0; base < n - k; base += kTB) {
         const uint32_t q = base + tid;                  // q-th position from the end
         const uint32_t p = n - 1u - q;
         const uint32_t f = (q < n - k && (in[p].c[axis] < pos)) ? 1u : 0u;
         uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
+        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (f) tp[n_tail + r] = p;
         n_tail += tot;
     }
@@ -303,13 +321,13 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     (void)tail_seen;
     float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
     // (a) positions < k: forward, hole rank by scan
-    for (uint32_t base = 0; base < k; base += kT) {
+    for (uint32_t base = 0; base < k; base += kTB) {
         const uint32_t p = base + tid;
         Proxy e;
         uint32_t f = 0;
         if (p < k) { e = in[p]; f = !(e.c[axis] < pos) ? 1u : 0u; }
         uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
+        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (p < k) {
             uint32_t dest;
             if (!f) dest = p;
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
     }
     // (b) positions >= k: from the end, tail rank by scan
     uint32_t tail_rank_base = 0;
-    for (uint32_t base = 0; base < n - k; base += kT) {
+    for (uint32_t base = 0; base < n - k; base += kTB) {
         const uint32_t q = base + tid;
         const uint32_t p = n - 1u - q;
         Proxy e;
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
         const bool valid = q < n - k;
         if (valid) { e = in[p]; f = (e.c[axis] < pos) ? 1u : 0u; }
         uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
+        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (valid) {
             uint32_t dest;
             if (f) dest = __hip_atomic_load(&hp[tail_rank_base + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -360,29 +378,39 @@ __global__ __launch_bounds__(kT) void build_level(BNode *bn, const uint32_t *__r
 // ---- nodes with 17..kWaveMax triangles: one wave64 per node, four nodes per workgroup; the same five steps with wave-level
 // reductions (f32 min/max and integer sums are exact in any order), a wave-private LDS region and no block barrier ----------
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// Wave-wide reductions of a value every lane holds (all 64 lanes active), result uniform.  Four DPP stages (lane ^ 1, lane ^ 2 inside a
+// quad, then the 8-lane and the 16-lane mirror: after each stage the mirrored partner holds the other half's partial result) leave
+// every row of 16 lanes with its row result; the four rows are combined through v_readlane.  (The __shfl_xor ladder these replace is
+// six dependent ds_bpermute round trips through the LDS crossbar per reduction, and a node makes about twenty of them.)
+template <class Op>
+__device__ __forceinline__ uint32_t wave_reduce_bits(uint32_t v, Op op) {
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
 __device__ __forceinline__ float wave_fmin(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    return __uint_as_float(wave_reduce_bits(__float_as_uint(v), [](uint32_t a, uint32_t b) { return __float_as_uint(fminf(__uint_as_float(a), __uint_as_float(b))); }));
 }
 __device__ __forceinline__ float wave_fmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    return __uint_as_float(wave_reduce_bits(__float_as_uint(v), [](uint32_t a, uint32_t b) { return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b))); }));
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return wave_reduce_bits(v, [](uint32_t a, uint32_t b) { return a + b; });
 }
 __device__ __forceinline__ uint32_t ballot_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 // Each lane keeps its (up to kWaveMax / 64) proxies in registers: the node is read from memory once and written once.
 // Slot j of lane l is position p = 64 j + l, so "increasing p" is slot-major / lane-minor order.
-constexpr int kSlots = (int)(kWaveMax / 64u);
-constexpr int kWaveNodes = 8;                      // nodes (= waves) per workgroup of build_level_wave
+constexpr int kWaveBigNodes = kWaveMax > 1024u ? 2 : 4;   // nodes (= waves) per workgroup of the largest build_level_wave instantiation (LDS: 8 B per triangle)
 struct WaveSplit { bool split; uint32_t k; Box3 A, B; };
+// kSlots = proxies per lane: the kernel picks the smallest instantiation that holds the node (most wave-class nodes have <= 64
+// triangles; walking 8 mostly empty slots through every stage was most of their cost)
+template <int kSlots>
 __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__restrict__ pin, Proxy *__restrict__ pout, uint32_t lane,
                                                uint32_t (*key)[8][6], uint32_t (*cnt)[8], uint32_t *hp, uint32_t *tp) {
     WaveSplit res;
@@ -392,17 +420,21 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
     const Proxy *in = pin + first;
     Proxy *out = pout + first;
 
-    float c0[kSlots], c1[kSlots], c2[kSlots], l0[kSlots], l1[kSlots], l2[kSlots], h0[kSlots], h1[kSlots], h2[kSlots];
+    // 7 registers per proxy: the centroid is (lo + hi) / 2 (make_proxies, scene.rs:125) and is re-derived where it is needed
+    float l0[kSlots], l1[kSlots], l2[kSlots], h0[kSlots], h1[kSlots], h2[kSlots];
     uint32_t id[kSlots];
+#define C0(j) ((l0[j] + h0[j]) / 2.0f)
+#define C1(j) ((l1[j] + h1[j]) / 2.0f)
+#define C2(j) ((l2[j] + h2[j]) / 2.0f)
 #pragma unroll
     for (int j = 0; j < kSlots; j++) {
         const uint32_t p = 64u * (uint32_t)j + lane;
         if (p < n) {
             const Proxy e = in[p];
-            c0[j] = e.c[0]; c1[j] = e.c[1]; c2[j] = e.c[2]; l0[j] = e.lo[0]; l1[j] = e.lo[1]; l2[j] = e.lo[2];
+            l0[j] = e.lo[0]; l1[j] = e.lo[1]; l2[j] = e.lo[2];
             h0[j] = e.hi[0]; h1[j] = e.hi[1]; h2[j] = e.hi[2]; id[j] = e.idx;
         } else {                                                      // neutral for every min / max below
-            c0[j] = c1[j] = c2[j] = 0.0f; l0[j] = l1[j] = l2[j] = F32_MAX; h0[j] = h1[j] = h2[j] = -F32_MAX; id[j] = 0u;
+            l0[j] = l1[j] = l2[j] = F32_MAX; h0[j] = h1[j] = h2[j] = -F32_MAX; id[j] = 0u;
         }
     }
     // ---- 1. centroid ranges + planes (bvh.rs:67-84) ----
@@ -412,8 +444,9 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
 #pragma unroll
         for (int j = 0; j < kSlots; j++)
             if (64u * (uint32_t)j + lane < n) {
-                mn[0] = fminf(mn[0], c0[j]); mx[0] = fmaxf(mx[0], c0[j]); mn[1] = fminf(mn[1], c1[j]); mx[1] = fmaxf(mx[1], c1[j]);
-                mn[2] = fminf(mn[2], c2[j]); mx[2] = fmaxf(mx[2], c2[j]);
+                const float a0 = C0(j), a1 = C1(j), a2 = C2(j);
+                mn[0] = fminf(mn[0], a0); mx[0] = fmaxf(mx[0], a0); mn[1] = fminf(mn[1], a1); mx[1] = fmaxf(mx[1], a1);
+                mn[2] = fminf(mn[2], a2); mx[2] = fmaxf(mx[2], a2);
             }
         for (int a = 0; a < 3; a++) { cmin[a] = wave_fmin(mn[a]); cmax[a] = wave_fmax(mx[a]); }
     }
@@ -428,7 +461,7 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
     for (int j = 0; j < kSlots; j++) {
         if (64u * (uint32_t)j >= n) break;                           // wave-uniform
         if (64u * (uint32_t)j + lane < n) {
-            const float cc[3] = {c0[j], c1[j], c2[j]};
+            const float cc[3] = {C0(j), C1(j), C2(j)};
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 if (!use[a]) continue;
@@ -480,68 +513,71 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
             const uint32_t p = 64u * (uint32_t)j + lane;
-            if (p < n) { Proxy e; e.c[0] = c0[j]; e.c[1] = c1[j]; e.c[2] = c2[j]; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j]; out[p] = e; }
+            if (p < n) { Proxy e; e.c[0] = C0(j); e.c[1] = C1(j); e.c[2] = C2(j); e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j]; out[p] = e; }
         }
         return res;
     }
     // ---- 4. the partition permutation (closed form of bvh.rs:99-108, see the header comment) ----
-    bool less[kSlots];
-#pragma unroll
-    for (int j = 0; j < kSlots; j++) {
-        const float c = axis == 0 ? c0[j] : (axis == 1 ? c1[j] : c2[j]);
-        less[j] = (64u * (uint32_t)j + lane < n) && (c < pos);
-    }
+    // Nothing per slot is kept besides the proxy itself: "c < pos" is re-evaluated and the ranks are re-derived from ballots in the
+    // second pass (two compares and a ballot cost less than the registers, which decide how many triangles a wave can hold).
+#define LESS(j) ((64u * (uint32_t)(j) + lane < n) && ((axis == 0 ? C0(j) : (axis == 1 ? C1(j) : C2(j))) < pos))
     if (!k_known) {                                                  // NaN parent cost with no finite candidate: count directly
         uint32_t cl = 0;
 #pragma unroll
-        for (int j = 0; j < kSlots; j++) cl += less[j] ? 1u : 0u;
+        for (int j = 0; j < kSlots; j++) cl += LESS(j) ? 1u : 0u;
         k = wave_sum(cl);
     }
-    uint32_t hole_rank[kSlots], tail_rank[kSlots];
     uint32_t n_holes = 0;
 #pragma unroll
     for (int j = 0; j < kSlots; j++) {                               // holes: positions < k holding ">=", increasing p
         const uint32_t p = 64u * (uint32_t)j + lane;
-        const bool f = p < k && !less[j];
+        const bool f = p < k && !LESS(j);
         const unsigned long long m = __ballot(f);
-        hole_rank[j] = n_holes + ballot_rank(m);
-        if (f) hp[hole_rank[j]] = p;
+        if (f) hp[n_holes + ballot_rank(m)] = p;
         n_holes += (uint32_t)__popcll(m);
     }
     uint32_t n_tail = 0;
 #pragma unroll
     for (int j = kSlots - 1; j >= 0; j--) {                          // tail "<": positions >= k holding "<", decreasing p
         const uint32_t p = 64u * (uint32_t)j + lane;
-        const bool f = p >= k && less[j];                            // (less[] is false beyond n)
+        const bool f = p >= k && LESS(j);                            // (false beyond n)
         const unsigned long long m = __ballot(f);
         const unsigned long long above = lane == 63u ? 0ull : (m >> (lane + 1u));
-        tail_rank[j] = n_tail + (uint32_t)__popcll(above);
-        if (f) tp[tail_rank[j]] = p;
+        if (f) tp[n_tail + (uint32_t)__popcll(above)] = p;
         n_tail += (uint32_t)__popcll(m);
     }
     wave_sync();
     const uint32_t t_last = n_holes ? tp[n_holes - 1u] : n;
     float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
+    uint32_t holes_before = 0, tail_through = 0;                     // holes in the slots below j; tail "<" in the slots up to and including j
 #pragma unroll
     for (int j = 0; j < kSlots; j++) {
         const uint32_t p = 64u * (uint32_t)j + lane;
+        const bool lt = LESS(j);
+        const unsigned long long mh = __ballot(p < k && !lt), mt = __ballot(p >= k && lt);
+        tail_through += (uint32_t)__popcll(mt);
         if (p < n) {
             uint32_t dest;
             if (p < k) {
                 dest = p;
-                if (!less[j]) { const uint32_t mm = hole_rank[j]; dest = (mm ? tp[mm - 1u] : n) - 1u; }
+                if (!lt) { const uint32_t mm = holes_before + ballot_rank(mh); dest = (mm ? tp[mm - 1u] : n) - 1u; }
             } else {
-                if (less[j]) dest = hp[tail_rank[j]];
+                if (lt) {
+                    const unsigned long long above = lane == 63u ? 0ull : (mt >> (lane + 1u));
+                    dest = hp[(n_tail - tail_through) + (uint32_t)__popcll(above)];
+                }
                 else if (p > t_last) dest = p - 1u;
                 else dest = (p == k) ? (t_last - 1u) : (p - 1u);
             }
-            Proxy e; e.c[0] = c0[j]; e.c[1] = c1[j]; e.c[2] = c2[j]; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j];
+            Proxy e; e.c[0] = C0(j); e.c[1] = C1(j); e.c[2] = C2(j); e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j];
             out[dest] = e;
-            const int side = less[j] ? 0 : 1;
+            const int side = lt ? 0 : 1;
             clo[side][0] = fminf(clo[side][0], l0[j]); clo[side][1] = fminf(clo[side][1], l1[j]); clo[side][2] = fminf(clo[side][2], l2[j]);
             chi[side][0] = fmaxf(chi[side][0], h0[j]); chi[side][1] = fmaxf(chi[side][1], h1[j]); chi[side][2] = fmaxf(chi[side][2], h2[j]);
         }
+        holes_before += (uint32_t)__popcll(mh);
     }
+#undef LESS
     for (int sd = 0; sd < 2; sd++)
         for (int q = 0; q < 3; q++) { clo[sd][q] = wave_fmin(clo[sd][q]); chi[sd][q] = wave_fmax(chi[sd][q]); }
     if (k == 0u || k == n) return res;                               // bvh.rs:110-113 (cannot happen with a finite best cost)
@@ -550,35 +586,56 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
     res.B = Box3{clo[1][0], clo[1][1], clo[1][2], chi[1][0], chi[1][1], chi[1][2]};
     return res;
 }
+#undef C0
+#undef C1
+#undef C2
 // ---- 5. children: the workgroup's waves hand their splits to wave 0, which allocates the child nodes and queues them with
 // ONE set of atomics per workgroup (a per-node atomic on the shared counters serialises in L2: ~6 ns each, which was the whole
 // cost of the deep levels) ----
-__global__ __launch_bounds__(64 * kWaveNodes, 4) void build_level_wave(BNode *bn, const uint32_t *__restrict__ list, uint32_t count,
+// Three instantiations walk the same class list on three streams, each taking the nodes with LO < n <= HI triangles (a wave whose
+// node belongs to another one sits out): <= 64 (one proxy per lane: a third of the registers, so 8 waves per SIMD -- a node is a
+// chain of dependent memory round trips, and most wave-class nodes are this small), <= 512 (8 proxies per lane, 4 waves per SIMD)
+// and <= kWaveMax (kWaveMax / 64 proxies per lane, 2 waves per SIMD, fewer nodes per workgroup for the LDS position lists).  Reading
+// a node once into registers and writing it once is what makes this kernel ~10x faster per triangle than build_level's eight
+// passes over global memory -- hence the wide range.
+template <uint32_t LO, uint32_t HI, int NODES, int MINW>
+__global__ __launch_bounds__(64 * NODES, MINW) void build_level_wave(BNode *bn, const uint32_t *__restrict__ list, uint32_t count,
                                                                       const Proxy *__restrict__ pin, Proxy *__restrict__ pout, Ctrl *ctrl,
                                                                       Lists ls, uint32_t next_parity) {
-    __shared__ uint32_t s_keyw[kWaveNodes][3][8][6];
-    __shared__ uint32_t s_cntw[kWaveNodes][3][8];
-    __shared__ uint32_t s_hp[kWaveNodes][kWaveMax], s_tp[kWaveNodes][kWaveMax];
-    __shared__ uint32_t s_node[kWaveNodes], s_first[kWaveNodes], s_n[kWaveNodes], s_k[kWaveNodes];
-    __shared__ Box3 s_box[kWaveNodes][2];
+    constexpr int kS = (int)(HI / 64u);
+    __shared__ uint32_t s_keyw[NODES][3][8][6];
+    __shared__ uint32_t s_cntw[NODES][3][8];
+    __shared__ uint32_t s_hp[NODES][HI], s_tp[NODES][HI];
+    __shared__ uint32_t s_node[NODES], s_first[NODES], s_n[NODES], s_k[NODES];
+    __shared__ Box3 s_box[NODES][2];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t item = blockIdx.x * (uint32_t)kWaveNodes + wv;
+    const uint32_t item = blockIdx.x * (uint32_t)NODES + wv;
     WaveSplit r;
     r.split = false; r.k = 0;
     uint32_t node_i = 0, first = 0, n = 0;
     if (item < count) {                                              // wave-uniform
         node_i = list[item];
-        const BNode nd = bn[node_i];
-        first = nd.first; n = nd.n;
-        r = wave_node(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+        n = bn[node_i].n;
+        if (n > LO && n <= HI) {                                     // wave-uniform
+            const BNode nd = bn[node_i];
+            first = nd.first;
+            if (kS >= 8 && n <= 4u * 64u) {                          // the smallest instantiation that holds the node
+                if (n <= 128u) r = wave_node<2>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+                else r = wave_node<4>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+            } else if (kS >= 32 && n <= 16u * 64u) {
+                r = wave_node<16>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+            } else {
+                r = wave_node<kS>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+            }
+        }
     }
     if (lane == 0u) {
-        s_node[wv] = node_i; s_first[wv] = first; s_n[wv] = n; s_k[wv] = r.split ? r.k : 0u;     // k == 0 marks "no split"
+        s_node[wv] = node_i; s_first[wv] = first; s_n[wv] = n; s_k[wv] = r.split ? r.k : 0u;     // k == 0 marks "no split" (or: not this kernel's node)
         s_box[wv][0] = r.A; s_box[wv][1] = r.B;
     }
     __syncthreads();
-    if (wv == 0u) {                                                  // lanes 0..kWaveNodes-1 each emit one node's children
-        const bool mine = lane < (uint32_t)kWaveNodes && s_k[lane] != 0u;
+    if (wv == 0u) {                                                  // lanes 0..NODES-1 each emit one node's children
+        const bool mine = lane < (uint32_t)NODES && s_k[lane] != 0u;
         if (mine) emit_children(bn, ctrl, ls, next_parity, s_node[lane], s_box[lane][0], s_box[lane][1], s_first[lane], s_k[lane], s_n[lane]);
     }
 }
@@ -673,7 +730,7 @@ __global__ __launch_bounds__(64) void build_subtree_tiny(BNode *bn, const uint32
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pre, o); if (t >= (uint32_t)o) pre += y; }
     uint32_t base = 0;
-    if (t == 63u) base = atomicAdd(&ctrl->pool_alloc, pre);
+    if (t == 63u) base = atomicAdd(&ctrl->pool_alloc.v, pre);
     base = __shfl(base, 63) + pre - need;
     if (!act) return;
 
@@ -757,7 +814,7 @@ __global__ __launch_bounds__(64) void build_subtree_tiny(BNode *bn, const uint32
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         const unsigned long long m = __ballot(true);
-        if (t == (uint32_t)(__ffsll((long long)m) - 1) && tot) atomicAdd(&ctrl->sub_nodes, tot);
+        if (t == (uint32_t)(__ffsll((long long)m) - 1) && tot) atomicAdd(&ctrl->sub_nodes.v, tot);
     }
 }
 
@@ -814,11 +871,11 @@ __global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, c
         }
         running += tot;
     }
-    if (threadIdx.x == 0) { chunk_begin[nb] = running; ctrl->n_chunks = running; }
+    if (threadIdx.x == 0) { chunk_begin[nb] = running; ctrl->n_chunks.v = running; }
 }
 __global__ __launch_bounds__(kT) void big_range(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_mn[3], s_mx[3];
-    if (blockIdx.x >= ctrl->n_chunks) return;
+    if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
@@ -846,7 +903,7 @@ __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch,
     __shared__ uint32_t s_cntc[kCopies][3][8];
     __shared__ float s_pos[3][8];
     __shared__ int s_use[3];
-    if (blockIdx.x >= ctrl->n_chunks) return;
+    if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
@@ -916,7 +973,7 @@ __global__ void big_choose(BigState *bs, uint32_t nb) {                         
 }
 __global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
-    if (blockIdx.x >= ctrl->n_chunks) return;
+    if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     if (!b->split || b->k_known) return;
@@ -930,7 +987,7 @@ __global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *c
 }
 __global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {   // holes / tail-"<" per chunk
     __shared__ uint32_t s_warp[4];
-    if (blockIdx.x >= ctrl->n_chunks) return;
+    if (blockIdx.x >= ctrl->n_chunks.v) return;
     ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     if (!b->split) return;
@@ -979,7 +1036,7 @@ __global__ __launch_bounds__(64) void big_scan(BigState *bs, ChunkInfo *ch, cons
 __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, uint32_t *hole_pos, uint32_t *tail_pos,
                                                const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
-    if (blockIdx.x >= ctrl->n_chunks) return;
+    if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     const BigState *b = bs + c.big;
     if (!b->split) return;
@@ -1009,7 +1066,7 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
                                                   const uint32_t *hole_pos, const uint32_t *tail_pos, const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
     __shared__ uint32_t s_ckey[2][6];
-    if (blockIdx.x >= ctrl->n_chunks) return;
+    if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     const Proxy *in = pin + b->first + c.off;
@@ -1146,13 +1203,11 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t sb = nullptr, sw = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
+    hipStream_t sb = nullptr, sb2 = nullptr, sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
+        hipStream_t all[] = {sb2, sw, sw2, sw3, st, sg, ss};
+        for (hipStream_t x : all) if (x && x != sb) (void)hipStreamDestroy(x);
         if (sb) (void)hipStreamDestroy(sb);
-        if (sw) (void)hipStreamDestroy(sw);
-        if (st) (void)hipStreamDestroy(st);
-        if (sg) (void)hipStreamDestroy(sg);
-        if (ss) (void)hipStreamDestroy(ss);
         void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -1190,19 +1245,25 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipStreamCreate(&sb));                          // blocking streams: ordered against the null stream's copies / launches
+    HIP_TRY(hipStreamCreate(&sb2));
     HIP_TRY(hipStreamCreate(&sw));
+    HIP_TRY(hipStreamCreate(&sw2));
+    HIP_TRY(hipStreamCreate(&sw3));
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
+#ifdef MIPT_BVH_ONE_STREAM                                  // diagnosis: every kernel alone on the GPU (tools/bvh_trace.sh)
+    { hipStream_t all[] = {sb2, sw, sw2, sw3, st, sg, ss}; for (hipStream_t x : all) (void)hipStreamDestroy(x); sb2 = sw = sw2 = sw3 = st = sg = ss = sb; }
+#endif
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
     Ctrl hc;
     memset(&hc, 0, sizeof hc);
-    hc.n_nodes = 1u;
+    hc.n_nodes.v = 1u;
     {                                                       // the root goes straight into its class list (parity 0)
         const int cls = n_tris > kBig ? CLS_BIG : (n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : (n_tris > kSub ? CLS_TINY : CLS_SUB)));
-        hc.cnt[0][cls] = 1u;
+        hc.cnt[0][cls].v = 1u;
         const uint32_t zero = 0u;
         HIP_TRY(hipMemcpy(ls.l[0][cls], &zero, 4, hipMemcpyHostToDevice));
     }
@@ -1216,7 +1277,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     uint32_t parity = 0;
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
-        const uint32_t nb = hc.cnt[parity][CLS_BIG];
+        const uint32_t nb = hc.cnt[parity][CLS_BIG].v;
         if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk);
                                                         // its own stream: these 11 launches overlap the level's block / wave / tiny kernels
             const uint32_t nc = n_tris / kChunk + nb;   // bound on sum(ceil(n_j / kChunk)); the real count lives in ctrl->n_chunks
@@ -1234,23 +1295,32 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
             hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
             hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
         }
-        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK], nwav = hc.cnt[parity][CLS_WAVE], ntin = hc.cnt[parity][CLS_TINY], nsub = hc.cnt[parity][CLS_SUB];
-        if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kT), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
-        if (nwav) hipLaunchKernelGGL(build_level_wave, dim3((nwav + (uint32_t)kWaveNodes - 1u) / (uint32_t)kWaveNodes), dim3(64 * kWaveNodes), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK].v, nwav = hc.cnt[parity][CLS_WAVE].v, ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
+        if (nblk) {
+            hipLaunchKernelGGL(build_level<1024>, dim3(nblk), dim3(1024), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
+            hipLaunchKernelGGL(build_level<256>, dim3(nblk), dim3(256), 0, sb2, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
+        }
+        if (nwav) {
+            const uint32_t g8 = (nwav + 7u) / 8u, g2 = (nwav + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes;
+            if (kWaveMax > 512u)
+                hipLaunchKernelGGL((build_level_wave<512u, kWaveMax, kWaveBigNodes, 2>), dim3(g2), dim3(64 * kWaveBigNodes), 0, sw3, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+            hipLaunchKernelGGL((build_level_wave<64u, (kWaveMax < 512u ? kWaveMax : 512u), 8, 4>), dim3(g8), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+            hipLaunchKernelGGL((build_level_wave<0u, 64u, 8, 8>), dim3(g8), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        }
         if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (nsub) hipLaunchKernelGGL(build_subtree_tiny, dim3((nsub + 63u) / 64u), dim3(64), 0, ss, d_bn, ls.l[parity][CLS_SUB], nsub, d_px[cur], d_px[0], d_px[1], d_pool, d_ctrl);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(h_ctrl, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));        // pinned target; also the level's barrier
         hc = *h_ctrl;
-        const uint32_t total = hc.n_nodes;
+        const uint32_t total = hc.n_nodes.v;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        hc.cnt[parity][0] = hc.cnt[parity][1] = hc.cnt[parity][2] = hc.cnt[parity][3] = hc.cnt[parity][4] = 0u;   // this level's lists are consumed: reset for level + 2
-        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, 20, nullptr));           // stream-ordered, no host round trip
+        for (int c = 0; c < 5; c++) hc.cnt[parity][c].v = 0u;   // this level's lists are consumed: reset for level + 2
+        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, 5 * sizeof(Pad32), nullptr));           // stream-ordered, no host round trip
         begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
     const uint32_t n_bn = end;                                  // nodes built level by level; the finished subtrees' nodes live in the pool
-    const uint32_t n_nodes = n_bn + hc.sub_nodes;
+    const uint32_t n_nodes = n_bn + hc.sub_nodes.v;
     lvl_begin.push_back(n_bn);
     if (n_nodes > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
     if (n_nodes > nodes_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: nodes_cap too small"); return MIPT_ERR_INVALID_ARG; }
