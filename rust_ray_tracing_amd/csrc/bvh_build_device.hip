@@ -33,7 +33,7 @@ namespace {
 
 constexpr int kT = 256;
 #ifndef MIPT_BVH_BLOCK_SPLIT
-#define MIPT_BVH_BLOCK_SPLIT 4096
+#define MIPT_BVH_BLOCK_SPLIT 8192
 #endif
 constexpr uint32_t kBlockSplit = MIPT_BVH_BLOCK_SPLIT;   // block-class nodes above this many triangles get 1024 threads (build_level)
 
@@ -62,7 +62,10 @@ struct alignas(128) Pad32 { uint32_t v; uint32_t pad[31]; };        // one count
 struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][5], pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
 struct Lists { uint32_t *l[2][5]; };
 
-struct Proxy { float c[3], lo[3], hi[3]; uint32_t idx; };            // 40 B
+struct alignas(16) Proxy {                                            // 32 B = two 16-B words
+    float lo[3]; uint32_t idx; float hi[3]; uint32_t pad;
+    __device__ __forceinline__ float c(int a) const { return (lo[a] + hi[a]) / 2.0f; }   // the centroid (scene.rs:125) is re-derived, not stored: a fifth less traffic in every pass
+};
 struct BNode {
     float lo[3], hi[3];
     uint32_t first, n;
@@ -149,11 +152,11 @@ __global__ void make_proxies(const MiptTriangle *tris, uint32_t n, Proxy *px, ui
     __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Proxy p;
-        p.idx = i;
+        p.idx = i; p.pad = 0u;
         for (int a = 0; a < 3; a++) {
             float mn = F32_MAX, mx = -F32_MAX;                                          // scene.rs:115-123, bvh.rs:185-194
             for (int v = 0; v < 3; v++) { const float q = (&tris[i].vertices[v].position.x)[a]; mn = fminf(mn, q); mx = fmaxf(mx, q); }
-            p.lo[a] = mn; p.hi[a] = mx; p.c[a] = (mn + mx) / 2.0f;                      // scene.rs:125
+            p.lo[a] = mn; p.hi[a] = mx;                                                 // scene.rs:125: see Proxy::c
             atomicMin(&s_lo[a], fkey(mn)); atomicMax(&s_hi[a], fkey(mx));
         }
         px[i] = p;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
     {
         float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
         for (uint32_t i = tid; i < n; i += kTB)
-            for (int a = 0; a < 3; a++) { const float c = in[i].c[a]; mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c); }
+            for (int a = 0; a < 3; a++) { const float c = in[i].c(a); mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c); }
         for (int a = 0; a < 3; a++) { atomicMin(&s_cmin[a], fkey(mn[a])); atomicMax(&s_cmax[a], fkey(mx[a])); }
     }
     __syncthreads();
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
         for (int a = 0; a < 3; a++) {
             if (!s_use[a]) continue;
             int k = 8;
-            for (int j = 1; j < 8; j++) if (p.c[a] < s_pos[a][j]) { k = j; break; }
+            for (int j = 1; j < 8; j++) if (p.c(a) < s_pos[a][j]) { k = j; break; }
             uint32_t *key = s_keyc[tid & (kCopies - 1u)][a][k - 1];
             for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
             atomicAdd(&s_cntc[tid & (kCopies - 1u)][a][k - 1], 1u);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
     if (s_k == kNone) {                                 // only when no candidate was finite (NaN parent cost): count directly
         __syncthreads();
         uint32_t cnt = 0;
-        for (uint32_t i = tid; i < n; i += kTB) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
+        for (uint32_t i = tid; i < n; i += kTB) cnt += (in[i].c(axis) < pos) ? 1u : 0u;
         uint32_t tot;
         (void)block_exscan<kTB / 64>(cnt, s_warp, &tot);
         if (tid == 0) s_k = tot;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
     uint32_t n_holes = 0;
     for (uint32_t base = 0; base < k; base += kTB) {
         const uint32_t p = base + tid;
-        const uint32_t f = (p < k && !(in[p].c[axis] < pos)) ? 1u : 0u;
+        const uint32_t f = (p < k && !(in[p].c(axis) < pos)) ? 1u : 0u;
         uint32_t tot;
         const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (f) hp[n_holes + r] = p;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
     for (uint32_t base = 0; base < n - k; base += kTB) {
         const uint32_t q = base + tid;                  // q-th position from the end
         const uint32_t p = n - 1u - q;
-        const uint32_t f = (q < n - k && (in[p].c[axis] < pos)) ? 1u : 0u;
+        const uint32_t f = (q < n - k && (in[p].c(axis) < pos)) ? 1u : 0u;
         uint32_t tot;
         const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (f) tp[n_tail + r] = p;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
         const uint32_t p = base + tid;
         Proxy e;
         uint32_t f = 0;
-        if (p < k) { e = in[p]; f = !(e.c[axis] < pos) ? 1u : 0u; }
+        if (p < k) { e = in[p]; f = !(e.c(axis) < pos) ? 1u : 0u; }
         uint32_t tot;
         const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (p < k) {
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
         Proxy e;
         uint32_t f = 0;
         const bool valid = q < n - k;
-        if (valid) { e = in[p]; f = (e.c[axis] < pos) ? 1u : 0u; }
+        if (valid) { e = in[p]; f = (e.c(axis) < pos) ? 1u : 0u; }
         uint32_t tot;
         const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
         if (valid) {
@@ -513,7 +516,7 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
             const uint32_t p = 64u * (uint32_t)j + lane;
-            if (p < n) { Proxy e; e.c[0] = C0(j); e.c[1] = C1(j); e.c[2] = C2(j); e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j]; out[p] = e; }
+            if (p < n) { Proxy e; e.pad = 0u; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j]; out[p] = e; }
         }
         return res;
     }
@@ -569,7 +572,7 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
                 else if (p > t_last) dest = p - 1u;
                 else dest = (p == k) ? (t_last - 1u) : (p - 1u);
             }
-            Proxy e; e.c[0] = C0(j); e.c[1] = C1(j); e.c[2] = C2(j); e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j];
+            Proxy e; e.pad = 0u; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j];
             out[dest] = e;
             const int side = lt ? 0 : 1;
             clo[side][0] = fminf(clo[side][0], l0[j]); clo[side][1] = fminf(clo[side][1], l1[j]); clo[side][2] = fminf(clo[side][2], l2[j]);
@@ -659,7 +662,7 @@ __global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, u
     float best_pos = 0.0f, best_cost = F32_MAX;
     for (int a = 0; a < 3; a++) {
         float cmin = F32_MAX, cmax = -F32_MAX;
-        for (uint32_t i = 0; i < n; i++) { const float c = in[i].c[a]; cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); }
+        for (uint32_t i = 0; i < n; i++) { const float c = in[i].c(a); cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); }
         if (cmin == cmax) continue;
         const float scale = (cmax - cmin) / 8.0f;
         for (int i = 1; i < 8; i++) {
@@ -669,7 +672,7 @@ __global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, u
             uint32_t lc = 0, rc = 0;
             for (uint32_t t = 0; t < n; t++) {                                            // evaluate_sah, bvh.rs:138-161
                 const Proxy p = in[t];
-                if (p.c[a] < pos) { grow(llo, lhi, p); lc++; } else { grow(rlo, rhi, p); rc++; }
+                if (p.c(a) < pos) { grow(llo, lhi, p); lc++; } else { grow(rlo, rhi, p); rc++; }
             }
             const float cost = (float)lc * box_area(llo, lhi) + (float)rc * box_area(rlo, rhi);
             const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
@@ -679,7 +682,7 @@ __global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, u
     if (best_cost >= parent_cost) return;                                                 // leaf (bvh.rs:94); range already copied
     uint32_t i = 0, j = n - 1u;                                                           // bvh.rs:99-108 on `out`
     while (i <= j) {
-        if (out[i].c[best_axis] < best_pos) i++;
+        if (out[i].c(best_axis) < best_pos) i++;
         else {
             const Proxy t = out[i]; out[i] = out[j]; out[j] = t;
             if (j == 0u) break;
@@ -805,8 +808,8 @@ __global__ __launch_bounds__(64) void build_subtree_tiny(BNode *bn, const uint32
     if (cnt) bn[node_i].size = cnt;
     for (uint32_t i = 0; i < n0; i++) {                                                        // the range in its final order, in both ping-pong buffers
         Proxy p;
-        for (int q = 0; q < 3; q++) { p.lo[q] = s_p[i][q][t]; p.hi[q] = s_p[i][3 + q][t]; p.c[q] = (p.lo[q] + p.hi[q]) / 2.0f; }
-        p.idx = __float_as_uint(s_p[i][6][t]);
+        for (int q = 0; q < 3; q++) { p.lo[q] = s_p[i][q][t]; p.hi[q] = s_p[i][3 + q][t]; }
+        p.idx = __float_as_uint(s_p[i][6][t]); p.pad = 0u;
         pa[first0 + i] = p; pb[first0 + i] = p;
     }
     {                                                                                          // subtree nodes made, one atomic per wave
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(kT) void big_range(BigState *bs, const ChunkInfo *c
     __syncthreads();
     float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
     for (uint32_t i = threadIdx.x; i < c.len; i += kT)
-        for (int a = 0; a < 3; a++) { const float v = in[i].c[a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+        for (int a = 0; a < 3; a++) { const float v = in[i].c(a); mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
     for (int a = 0; a < 3; a++) { atomicMin(&s_mn[a], fkey(mn[a])); atomicMax(&s_mx[a], fkey(mx[a])); }
     __syncthreads();
     if (threadIdx.x < 3) { atomicMin(&b->cmin[threadIdx.x], s_mn[threadIdx.x]); atomicMax(&b->cmax[threadIdx.x], s_mx[threadIdx.x]); }
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch,
         for (int a = 0; a < 3; a++) {
             if (!s_use[a]) continue;
             int k = 8;
-            for (int j = 1; j < 8; j++) if (p.c[a] < s_pos[a][j]) { k = j; break; }
+            for (int j = 1; j < 8; j++) if (p.c(a) < s_pos[a][j]) { k = j; break; }
             uint32_t *key = s_keyc[threadIdx.x & (kCopies - 1u)][a][k - 1];
             for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
             atomicAdd(&s_cntc[threadIdx.x & (kCopies - 1u)][a][k - 1], 1u);
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *c
     const Proxy *in = pin + b->first + c.off;
     const int axis = b->axis; const float pos = b->splitpos;
     uint32_t cnt = 0;
-    for (uint32_t i = threadIdx.x; i < c.len; i += kT) cnt += (in[i].c[axis] < pos) ? 1u : 0u;
+    for (uint32_t i = threadIdx.x; i < c.len; i += kT) cnt += (in[i].c(axis) < pos) ? 1u : 0u;
     uint32_t tot;
     (void)block_exscan(cnt, s_warp, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(&b->k, tot);
@@ -996,7 +999,7 @@ __global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, co
     uint32_t holes = 0, tails = 0;
     for (uint32_t i = threadIdx.x; i < c.len; i += kT) {
         const uint32_t p = c.off + i;
-        const bool l = in[i].c[axis] < pos;
+        const bool l = in[i].c(axis) < pos;
         holes += (p < k && !l) ? 1u : 0u;
         tails += (p >= k && l) ? 1u : 0u;
     }
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkIn
     uint32_t hb = c.hole_base, tb = c.tail_base;
     for (uint32_t base = 0; base < c.len; base += kT) {                 // holes: increasing p
         const uint32_t i = base + threadIdx.x, p = c.off + i;
-        const uint32_t f = (i < c.len && p < k && !(in[i].c[axis] < pos)) ? 1u : 0u;
+        const uint32_t f = (i < c.len && p < k && !(in[i].c(axis) < pos)) ? 1u : 0u;
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (f) hp[hb + r] = p;
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkIn
     for (uint32_t base = 0; base < c.len; base += kT) {                 // tail "<": decreasing p
         const uint32_t q = base + threadIdx.x;
         const uint32_t i = c.len - 1u - q, p = c.off + i;
-        const uint32_t f = (q < c.len && p >= k && (in[i].c[axis] < pos)) ? 1u : 0u;
+        const uint32_t f = (q < c.len && p >= k && (in[i].c(axis) < pos)) ? 1u : 0u;
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (f) tp[tb + r] = p;
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
         const bool valid = i < c.len && p < k;
         Proxy e;
         uint32_t f = 0;
-        if (valid) { e = in[i]; f = !(e.c[axis] < pos) ? 1u : 0u; }
+        if (valid) { e = in[i]; f = !(e.c(axis) < pos) ? 1u : 0u; }
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (valid) {
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
         const bool valid = q < c.len && p >= k;
         Proxy e;
         uint32_t f = 0;
-        if (valid) { e = in[i]; f = (e.c[axis] < pos) ? 1u : 0u; }
+        if (valid) { e = in[i]; f = (e.c(axis) < pos) ? 1u : 0u; }
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (valid) {
@@ -1205,9 +1208,12 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t sb = nullptr, sb2 = nullptr, sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
-        hipStream_t all[] = {sb2, sw, sw2, sw3, st, sg, ss};
-        for (hipStream_t x : all) if (x && x != sb) (void)hipStreamDestroy(x);
-        if (sb) (void)hipStreamDestroy(sb);
+        hipStream_t all[] = {sb, sb2, sw, sw2, sw3, st, sg, ss};
+        for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) {
+            bool seen = false;
+            for (size_t j = 0; j < i; j++) seen = seen || all[j] == all[i];
+            if (all[i] && !seen) (void)hipStreamDestroy(all[i]);
+        }
         void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -1252,6 +1258,13 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
+#ifdef MIPT_BVH_MERGE                                       // experiment: fewer streams (bit 0: the wave kernels share one, bit 1: tiny + sub share one, bit 2: all five share one)
+    {
+        hipStream_t *grp[3][5] = {{&sw2, &sw3, nullptr, nullptr, nullptr}, {&ss, nullptr, nullptr, nullptr, nullptr}, {&sw2, &sw3, &st, &ss, nullptr}};
+        hipStream_t into[3] = {sw, st, sw};
+        for (int b = 2; b >= 0; b--) if ((MIPT_BVH_MERGE >> b) & 1) for (hipStream_t **q = grp[b]; *q; q++) { if (**q != into[b]) { (void)hipStreamDestroy(**q); **q = into[b]; } }
+    }
+#endif
 #ifdef MIPT_BVH_ONE_STREAM                                  // diagnosis: every kernel alone on the GPU (tools/bvh_trace.sh)
     { hipStream_t all[] = {sb2, sw, sw2, sw3, st, sg, ss}; for (hipStream_t x : all) (void)hipStreamDestroy(x); sb2 = sw = sw2 = sw3 = st = sg = ss = sb; }
 #endif
