@@ -32,11 +32,6 @@ void mipt_internal_set_error(const char *msg);
 namespace {
 
 constexpr int kT = 256;
-#ifndef MIPT_BVH_BLOCK_SPLIT
-#define MIPT_BVH_BLOCK_SPLIT 8192
-#endif
-constexpr uint32_t kBlockSplit = MIPT_BVH_BLOCK_SPLIT;   // block-class nodes above this many triangles get 1024 threads (build_level)
-
 constexpr float F32_MAX = FLT_MAX;
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kSubFlag = 0x80000000u;   // BNode::left = kSubFlag | pool index: the node's whole subtree lives in the pool (build_subtree_tiny)
@@ -172,11 +167,9 @@ __global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
     bn[0] = r;
 }
 
-// one workgroup per node of this level's CLS_BLOCK list.  A level lasts as long as its largest node (a 32 k-triangle node is 128
-// trips through each of the eight loops below for 256 threads: ~2 ms), while most block-class nodes have ~1 k triangles and want
-// many small workgroups: so two instantiations walk the same list on two streams -- kTB = 1024 threads for nodes above kBlockSplit
-// triangles, 256 for the rest -- and a workgroup whose node belongs to the other one leaves at once.
-template <int kTB>
+// one workgroup per node of this level's CLS_BLOCK list (kWaveMax < n <= kBig).  (A 1024-thread instantiation for the larger of
+// these nodes was measured: one such workgroup per CU is slower than six of 256 threads, 28.3 vs 27.4 ms.)
+constexpr int kTB = kT;
 __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__restrict__ list, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
                                                   uint32_t *hole_pos, uint32_t *tail_pos, Ctrl *ctrl, Lists ls, uint32_t next_parity) {
     // per axis, per bin: lo.xyz (min keys), hi.xyz (max keys) and the count.  kCopies private copies (thread & 7 picks one,
@@ -195,7 +188,6 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
     __shared__ uint32_t s_k;
 
     const uint32_t node_i = list[blockIdx.x];
-    if ((bn[node_i].n > kBlockSplit) != (kTB > 256)) return;          // uniform over the workgroup
     const BNode nd = bn[node_i];
     const uint32_t first = nd.first, n = nd.n, tid = threadIdx.x;
     const Proxy *in = pin + first;
@@ -1206,9 +1198,9 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     ChunkInfo *d_chunks = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t sb = nullptr, sb2 = nullptr, sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
+    hipStream_t sb = nullptr, sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
-        hipStream_t all[] = {sb, sb2, sw, sw2, sw3, st, sg, ss};
+        hipStream_t all[] = {sb, sw, sw2, sw3, st, sg, ss};
         for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) {
             bool seen = false;
             for (size_t j = 0; j < i; j++) seen = seen || all[j] == all[i];
@@ -1251,22 +1243,14 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipStreamCreate(&sb));                          // blocking streams: ordered against the null stream's copies / launches
-    HIP_TRY(hipStreamCreate(&sb2));
     HIP_TRY(hipStreamCreate(&sw));
     HIP_TRY(hipStreamCreate(&sw2));
     HIP_TRY(hipStreamCreate(&sw3));
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
-#ifdef MIPT_BVH_MERGE                                       // experiment: fewer streams (bit 0: the wave kernels share one, bit 1: tiny + sub share one, bit 2: all five share one)
-    {
-        hipStream_t *grp[3][5] = {{&sw2, &sw3, nullptr, nullptr, nullptr}, {&ss, nullptr, nullptr, nullptr, nullptr}, {&sw2, &sw3, &st, &ss, nullptr}};
-        hipStream_t into[3] = {sw, st, sw};
-        for (int b = 2; b >= 0; b--) if ((MIPT_BVH_MERGE >> b) & 1) for (hipStream_t **q = grp[b]; *q; q++) { if (**q != into[b]) { (void)hipStreamDestroy(**q); **q = into[b]; } }
-    }
-#endif
 #ifdef MIPT_BVH_ONE_STREAM                                  // diagnosis: every kernel alone on the GPU (tools/bvh_trace.sh)
-    { hipStream_t all[] = {sb2, sw, sw2, sw3, st, sg, ss}; for (hipStream_t x : all) (void)hipStreamDestroy(x); sb2 = sw = sw2 = sw3 = st = sg = ss = sb; }
+    { hipStream_t all[] = {sw, sw2, sw3, st, sg, ss}; for (hipStream_t x : all) (void)hipStreamDestroy(x); sw = sw2 = sw3 = st = sg = ss = sb; }
 #endif
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -1309,10 +1293,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
             hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
         }
         const uint32_t nblk = hc.cnt[parity][CLS_BLOCK].v, nwav = hc.cnt[parity][CLS_WAVE].v, ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
-        if (nblk) {
-            hipLaunchKernelGGL(build_level<1024>, dim3(nblk), dim3(1024), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
-            hipLaunchKernelGGL(build_level<256>, dim3(nblk), dim3(256), 0, sb2, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
-        }
+        if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kTB), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
         if (nwav) {
             const uint32_t g8 = (nwav + 7u) / 8u, g2 = (nwav + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes;
             if (kWaveMax > 512u)
