@@ -490,6 +490,10 @@ def main():
             del ref_buf
         result["parity"] = par
 
+    # outside the timed region, for the record: what it took to get the scene onto the GPU(s) (device BVH build)
+    result["scene_setup"] = {"device_bvh_build_ms": round(float(bvh_ms), 2), "device_bvh_call_s": round(t2 - t1, 2), "scene_upload_s": round(t3 - t2, 2),
+                             "note": "BVH::build (bvh.rs:13-161) on the GPU, identical node array and triangle order (tests/test_gpu_more.py); "
+                                     "the call includes the 1.1 GB host <-> device copies of the triangle array"}
     # ---- N = 1: the in-library multi-GPU path (mipt_render_multi: RCCL communicator + gather / reduce behind the C ABI) ----
     if rank == 0 and world == 1 and not single and not args.no_render_multi:
         try:
