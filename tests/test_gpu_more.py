@@ -580,8 +580,9 @@ def test_device_bvh_builder_matches_host(rrt, orc, kind, kw):
 def test_device_bvh_builder_random_soups(rrt):
     from rust_ray_tracing_amd import TRIANGLE
     rng = np.random.default_rng(5)
-    for it in range(25):
-        n = int(rng.integers(1, 3000))
+    for it in range(30):
+        # sizes across every class of the device builder: one thread (<= 16), one wave (<= 2048), one workgroup (<= 8192), many workgroups
+        n = int(rng.integers(1, 3000)) if it % 5 != 4 else int(rng.integers(3000, 40000))
         scale = float(rng.choice([1e-3, 1.0, 1e3]))
         p = rng.standard_normal((n, 1, 3)) * scale * 5 + rng.standard_normal((n, 3, 3)) * scale * rng.random((n, 1, 1))
         if it % 2:
