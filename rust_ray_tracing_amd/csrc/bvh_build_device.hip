@@ -74,6 +74,11 @@ struct BNode {
 __device__ __forceinline__ uint32_t fkey(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float funkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
+// LDS min / max that first looks: after a bin's first few hundred triangles nearly none of them moves the bin's box, and a plain LDS
+// read costs a fraction of an LDS atomic that 8+ lanes of the wave aim at one address.  A stale read only makes the atomic redundant.
+__device__ __forceinline__ void lds_min(uint32_t *p, uint32_t v) { if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(p, v); }
+__device__ __forceinline__ void lds_max(uint32_t *p, uint32_t v) { if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(p, v); }
+
 __device__ __forceinline__ float box_area(const float *lo, const float *hi) {        // Node::surface_area, bvh.rs:196-203
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     return (ex * ez) + (ex * ey) + (ez * ey);
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__
             int k = 8;
             for (int j = 1; j < 8; j++) if (p.c(a) < s_pos[a][j]) { k = j; break; }
             uint32_t *key = s_keyc[tid & (kCopies - 1u)][a][k - 1];
-            for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
+            for (int q = 0; q < 3; q++) { lds_min(&key[q], fkey(p.lo[q])); lds_max(&key[3 + q], fkey(p.hi[q])); }
             atomicAdd(&s_cntc[tid & (kCopies - 1u)][a][k - 1], 1u);
         }
     }
@@ -463,8 +468,8 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
                 int k = 8;
                 for (int q = 7; q >= 1; q--) if (cc[a] < cmin[a] + (float)q * scale[a]) k = q;      // first plane the centroid is below
                 uint32_t *kk = key[a][k - 1];
-                atomicMin(&kk[0], fkey(l0[j])); atomicMin(&kk[1], fkey(l1[j])); atomicMin(&kk[2], fkey(l2[j]));
-                atomicMax(&kk[3], fkey(h0[j])); atomicMax(&kk[4], fkey(h1[j])); atomicMax(&kk[5], fkey(h2[j]));
+                lds_min(&kk[0], fkey(l0[j])); lds_min(&kk[1], fkey(l1[j])); lds_min(&kk[2], fkey(l2[j]));
+                lds_max(&kk[3], fkey(h0[j])); lds_max(&kk[4], fkey(h1[j])); lds_max(&kk[5], fkey(h2[j]));
                 atomicAdd(&cnt[a][k - 1], 1u);
             }
         }
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch,
             int k = 8;
             for (int j = 1; j < 8; j++) if (p.c(a) < s_pos[a][j]) { k = j; break; }
             uint32_t *key = s_keyc[threadIdx.x & (kCopies - 1u)][a][k - 1];
-            for (int q = 0; q < 3; q++) { atomicMin(&key[q], fkey(p.lo[q])); atomicMax(&key[3 + q], fkey(p.hi[q])); }
+            for (int q = 0; q < 3; q++) { lds_min(&key[q], fkey(p.lo[q])); lds_max(&key[3 + q], fkey(p.hi[q])); }
             atomicAdd(&s_cntc[threadIdx.x & (kCopies - 1u)][a][k - 1], 1u);
         }
     }
