@@ -641,25 +641,39 @@ __global__ __launch_bounds__(64 * NODES, MINW) void build_level_wave(BNode *bn, 
 }
 
 // ---- nodes with <= kTiny triangles: one thread per node, the reference's own loops (bvh.rs:56-161) on the proxies ----------
-__device__ __forceinline__ void grow(float *lo, float *hi, const Proxy &p) {
-    for (int q = 0; q < 3; q++) { lo[q] = fminf(lo[q], p.lo[q]); hi[q] = fmaxf(hi[q], p.hi[q]); }
 }
-__global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, uint32_t count, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
+// The node's proxies are staged in LDS ([slot][word][thread]: conflict-free) -- the 21 candidate sweeps and the in-place partition
+// were a chain of ~300 dependent global-memory reads per thread before, which is what a level cost whenever it had such nodes.
+__global__ __launch_bounds__(64) void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, uint32_t count, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
                                  Ctrl *ctrl, Lists ls, uint32_t next_parity) {
-    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_p[kTiny][7][64];                   // lo.xyz, hi.xyz, idx (as bits)
+    const uint32_t t = threadIdx.x, item = blockIdx.x * 64u + t;
     if (item >= count) return;
     const uint32_t node_i = list[item];
     const BNode nd = bn[node_i];
     const uint32_t n = nd.n;
     const Proxy *in = pin + nd.first;
     Proxy *out = pout + nd.first;
-    for (uint32_t i = 0; i < n; i++) out[i] = in[i];
+    for (uint32_t i = 0; i < n; i++) {
+        const Proxy p = in[i];
+        for (int q = 0; q < 3; q++) { s_p[i][q][t] = p.lo[q]; s_p[i][3 + q][t] = p.hi[q]; }
+        s_p[i][6][t] = __uint_as_float(p.idx);
+    }
+    auto cen = [&](uint32_t i, int a) { return (s_p[i][a][t] + s_p[i][3 + a][t]) / 2.0f; };
+    auto store = [&]() {                                  // the range in its current order
+        for (uint32_t i = 0; i < n; i++) {
+            Proxy p;
+            for (int q = 0; q < 3; q++) { p.lo[q] = s_p[i][q][t]; p.hi[q] = s_p[i][3 + q][t]; }
+            p.idx = __float_as_uint(s_p[i][6][t]); p.pad = 0u;
+            out[i] = p;
+        }
+    };
     const float parent_cost = (float)n * box_area(nd.lo, nd.hi);
     int best_axis = 0;
     float best_pos = 0.0f, best_cost = F32_MAX;
     for (int a = 0; a < 3; a++) {
         float cmin = F32_MAX, cmax = -F32_MAX;
-        for (uint32_t i = 0; i < n; i++) { const float c = in[i].c(a); cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); }
+        for (uint32_t i = 0; i < n; i++) { const float c = cen(i, a); cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); }
         if (cmin == cmax) continue;
         const float scale = (cmax - cmin) / 8.0f;
         for (int i = 1; i < 8; i++) {
@@ -667,33 +681,39 @@ __global__ void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, u
             float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
             float rlo[3] = {F32_MAX, F32_MAX, F32_MAX}, rhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
             uint32_t lc = 0, rc = 0;
-            for (uint32_t t = 0; t < n; t++) {                                            // evaluate_sah, bvh.rs:138-161
-                const Proxy p = in[t];
-                if (p.c(a) < pos) { grow(llo, lhi, p); lc++; } else { grow(rlo, rhi, p); rc++; }
+            for (uint32_t j = 0; j < n; j++) {                                            // evaluate_sah, bvh.rs:138-161
+                const bool left = cen(j, a) < pos;
+                for (int q = 0; q < 3; q++) {
+                    const float pl = s_p[j][q][t], ph = s_p[j][3 + q][t];
+                    if (left) { llo[q] = fminf(llo[q], pl); lhi[q] = fmaxf(lhi[q], ph); }
+                    else { rlo[q] = fminf(rlo[q], pl); rhi[q] = fmaxf(rhi[q], ph); }
+                }
+                if (left) lc++; else rc++;
             }
             const float cost = (float)lc * box_area(llo, lhi) + (float)rc * box_area(rlo, rhi);
             const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
             if (split_cost < best_cost) { best_axis = a; best_pos = pos; best_cost = split_cost; }
         }
     }
-    if (best_cost >= parent_cost) return;                                                 // leaf (bvh.rs:94); range already copied
-    uint32_t i = 0, j = n - 1u;                                                           // bvh.rs:99-108 on `out`
+    if (best_cost >= parent_cost) { store(); return; }                                    // leaf (bvh.rs:94): the range unchanged
+    uint32_t i = 0, j = n - 1u;                                                           // bvh.rs:99-108, in place
     while (i <= j) {
-        if (out[i].c(best_axis) < best_pos) i++;
+        if (cen(i, best_axis) < best_pos) i++;
         else {
-            const Proxy t = out[i]; out[i] = out[j]; out[j] = t;
+            for (int w = 0; w < 7; w++) { const float x = s_p[i][w][t]; s_p[i][w][t] = s_p[j][w][t]; s_p[j][w][t] = x; }
             if (j == 0u) break;
             j--;
         }
     }
     const uint32_t k = i;
-    if (k == 0u || k == n) return;
-    BNode a, b;
-    for (int q = 0; q < 3; q++) { a.lo[q] = F32_MAX; a.hi[q] = -F32_MAX; b.lo[q] = F32_MAX; b.hi[q] = -F32_MAX; }
-    for (uint32_t t = 0; t < k; t++) grow(a.lo, a.hi, out[t]);
-    for (uint32_t t = k; t < n; t++) grow(b.lo, b.hi, out[t]);
-    emit_children(bn, ctrl, ls, next_parity, node_i, Box3{a.lo[0], a.lo[1], a.lo[2], a.hi[0], a.hi[1], a.hi[2]},
-                  Box3{b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]}, nd.first, k, n);
+    store();
+    if (k == 0u || k == n) return;                                                        // bvh.rs:110-113
+    float alo[3], ahi[3], blo[3], bhi[3];
+    for (int q = 0; q < 3; q++) { alo[q] = F32_MAX; ahi[q] = -F32_MAX; blo[q] = F32_MAX; bhi[q] = -F32_MAX; }
+    for (uint32_t u = 0; u < k; u++) for (int q = 0; q < 3; q++) { alo[q] = fminf(alo[q], s_p[u][q][t]); ahi[q] = fmaxf(ahi[q], s_p[u][3 + q][t]); }
+    for (uint32_t u = k; u < n; u++) for (int q = 0; q < 3; q++) { blo[q] = fminf(blo[q], s_p[u][q][t]); bhi[q] = fmaxf(bhi[q], s_p[u][3 + q][t]); }
+    emit_children(bn, ctrl, ls, next_parity, node_i, Box3{alo[0], alo[1], alo[2], ahi[0], ahi[1], ahi[2]},
+                  Box3{blo[0], blo[1], blo[2], bhi[0], bhi[1], bhi[2]}, nd.first, k, n);
 }
 
 // ---- nodes with <= kSub triangles: one thread builds the node's WHOLE subtree (round 3) --------------------------------
@@ -1306,7 +1326,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
             hipLaunchKernelGGL((build_level_wave<64u, (kWaveMax < 512u ? kWaveMax : 512u), 8, 4>), dim3(g8), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
             hipLaunchKernelGGL((build_level_wave<0u, 64u, 8, 8>), dim3(g8), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         }
-        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 255u) / 256u), dim3(256), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 63u) / 64u), dim3(64), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (nsub) hipLaunchKernelGGL(build_subtree_tiny, dim3((nsub + 63u) / 64u), dim3(64), 0, ss, d_bn, ls.l[parity][CLS_SUB], nsub, d_px[cur], d_px[0], d_px[1], d_pool, d_ctrl);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(h_ctrl, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));        // pinned target; also the level's barrier
