@@ -641,7 +641,6 @@ __global__ __launch_bounds__(64 * NODES, MINW) void build_level_wave(BNode *bn, 
 }
 
 // ---- nodes with <= kTiny triangles: one thread per node, the reference's own loops (bvh.rs:56-161) on the proxies ----------
-}
 // The node's proxies are staged in LDS ([slot][word][thread]: conflict-free) -- the 21 candidate sweeps and the in-place partition
 // were a chain of ~300 dependent global-memory reads per thread before, which is what a level cost whenever it had such nodes.
 __global__ __launch_bounds__(64) void build_level_tiny(BNode *bn, const uint32_t *__restrict__ list, uint32_t count, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
