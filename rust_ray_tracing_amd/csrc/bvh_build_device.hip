@@ -50,12 +50,13 @@ constexpr uint32_t kSub = 8;               // nodes this small: ONE thread finis
 constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
 constexpr uint32_t kWaveMax = MIPT_BVH_WAVEMAX;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
-enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3, CLS_SUB = 4 };
+enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3, CLS_SUB = 4, CLS_WAVE_M = 5, CLS_WAVE_L = 6, kClasses = 7 };   // CLS_WAVE: 17..64, _M: 65..512, _L: 513..kWaveMax triangles
+constexpr uint32_t kWaveS = 64u, kWaveM = 512u;
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
 // children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
 struct alignas(128) Pad32 { uint32_t v; uint32_t pad[31]; };        // one counter per 128-B line: atomics on one line serialise, whichever word they hit
-struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][5], pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
-struct Lists { uint32_t *l[2][5]; };
+struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][kClasses], pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
+struct Lists { uint32_t *l[2][kClasses]; };
 
 struct alignas(16) Proxy {                                            // 32 B = two 16-B words
     float lo[3]; uint32_t idx; float hi[3]; uint32_t pad;
@@ -87,7 +88,14 @@ __device__ __forceinline__ float box_area(const float *lo, const float *hi) {   
 // Queue the two children of every active lane for the next level.  One atomic per class per wave: the lanes are ranked
 // with ballots (a per-lane atomicAdd on a per-lane class counter is not aggregated by the compiler and serialises in L2:
 // measured 30x slower on the deep levels).  Works under divergence -- only the lanes that reach this point take part.
-__device__ __forceinline__ uint32_t node_class(uint32_t n) { return n > kBig ? (uint32_t)CLS_BIG : (n > kWaveMax ? (uint32_t)CLS_BLOCK : (n > kTiny ? (uint32_t)CLS_WAVE : (n > kSub ? (uint32_t)CLS_TINY : (uint32_t)CLS_SUB))); }
+__host__ __device__ __forceinline__ uint32_t node_class(uint32_t n) {
+    if (n > kBig) return (uint32_t)CLS_BIG;
+    if (n > kWaveMax) return (uint32_t)CLS_BLOCK;
+    if (n > kWaveM) return (uint32_t)CLS_WAVE_L;
+    if (n > kWaveS) return (uint32_t)CLS_WAVE_M;
+    if (n > kTiny) return (uint32_t)CLS_WAVE;
+    return n > kSub ? (uint32_t)CLS_TINY : (uint32_t)CLS_SUB;
+}
 __device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -96,18 +104,18 @@ __device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint
     const unsigned long long active = __ballot(true);
     const int leader = (int)__ffsll((long long)active) - 1;
     const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long ma[5], mb[5];
-    uint32_t slot0[5];
+    unsigned long long ma[kClasses], mb[kClasses];
+    uint32_t slot0[kClasses];
 #pragma unroll
-    for (uint32_t c = 0; c < 5u; c++) { ma[c] = __ballot(ca == c); mb[c] = __ballot(cb == c); }
+    for (uint32_t c = 0; c < (uint32_t)kClasses; c++) { ma[c] = __ballot(ca == c); mb[c] = __ballot(cb == c); }
 #pragma unroll
-    for (uint32_t c = 0; c < 5u; c++) {                              // all the wave's list atomics in flight together: one round trip, not one per class
+    for (uint32_t c = 0; c < (uint32_t)kClasses; c++) {               // all the wave's list atomics in flight together: one round trip, not one per class
         const uint32_t tot = (uint32_t)__popcll(ma[c]) + (uint32_t)__popcll(mb[c]);
         slot0[c] = 0;
         if (tot != 0u && (int)lane == leader) slot0[c] = atomicAdd(&ctrl->cnt[parity][c].v, tot);
     }
 #pragma unroll
-    for (uint32_t c = 0; c < 5u; c++) {
+    for (uint32_t c = 0; c < (uint32_t)kClasses; c++) {
         if ((ma[c] | mb[c]) == 0ull) continue;
         const uint32_t s0 = __shfl(slot0[c], leader);
         uint32_t *list = ls.l[parity][c];
@@ -592,8 +600,7 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
 // ---- 5. children: the workgroup's waves hand their splits to wave 0, which allocates the child nodes and queues them with
 // ONE set of atomics per workgroup (a per-node atomic on the shared counters serialises in L2: ~6 ns each, which was the whole
 // cost of the deep levels) ----
-// Three instantiations walk the same class list on three streams, each taking the nodes with LO < n <= HI triangles (a wave whose
-// node belongs to another one sits out): <= 64 (one proxy per lane: a third of the registers, so 8 waves per SIMD -- a node is a
+// Three instantiations, each with its own class list and stream, take the nodes with LO < n <= HI triangles: <= 64 (one proxy per lane: a third of the registers, so 8 waves per SIMD -- a node is a
 // chain of dependent memory round trips, and most wave-class nodes are this small), <= 512 (8 proxies per lane, 4 waves per SIMD)
 // and <= kWaveMax (kWaveMax / 64 proxies per lane, 2 waves per SIMD, fewer nodes per workgroup for the LDS position lists).  Reading
 // a node once into registers and writing it once is what makes this kernel ~10x faster per triangle than build_level's eight
@@ -1253,12 +1260,15 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     // work lists: a level has at most min(2^level, n_tris) nodes; a class list never holds more nodes than triangles / its
     // smallest node... sized by the simple bound n_tris + 1 per (parity, class)
     const size_t list_cap = (size_t)n_tris + 1u;
-    HIP_TRY(hipMalloc((void **)&d_lists, (8 * list_cap + 2 * (size_t)big_cap) * 4));
+    HIP_TRY(hipMalloc((void **)&d_lists, (2 * (size_t)(kClasses - 1) * list_cap + 2 * (size_t)big_cap) * 4));
     Lists ls;
     for (int pa = 0; pa < 2; pa++) {
-        for (int c = 0; c < 3; c++) ls.l[pa][c] = d_lists + (size_t)(pa * 4 + c) * list_cap;
-        ls.l[pa][CLS_SUB] = d_lists + (size_t)(pa * 4 + 3) * list_cap;
-        ls.l[pa][CLS_BIG] = d_lists + 8 * list_cap + (size_t)pa * big_cap;
+        int slot = 0;
+        for (int c = 0; c < kClasses; c++) {
+            if (c == CLS_BIG) continue;
+            ls.l[pa][c] = d_lists + (size_t)(pa * (kClasses - 1) + slot++) * list_cap;
+        }
+        ls.l[pa][CLS_BIG] = d_lists + 2 * (size_t)(kClasses - 1) * list_cap + (size_t)pa * big_cap;
     }
     HIP_TRY(hipMalloc((void **)&d_root, 24));
     HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
@@ -1283,7 +1293,7 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     memset(&hc, 0, sizeof hc);
     hc.n_nodes.v = 1u;
     {                                                       // the root goes straight into its class list (parity 0)
-        const int cls = n_tris > kBig ? CLS_BIG : (n_tris > kWaveMax ? CLS_BLOCK : (n_tris > kTiny ? CLS_WAVE : (n_tris > kSub ? CLS_TINY : CLS_SUB)));
+        const int cls = (int)node_class(n_tris);
         hc.cnt[0][cls].v = 1u;
         const uint32_t zero = 0u;
         HIP_TRY(hipMemcpy(ls.l[0][cls], &zero, 4, hipMemcpyHostToDevice));
@@ -1316,15 +1326,13 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
             hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
             hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
         }
-        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK].v, nwav = hc.cnt[parity][CLS_WAVE].v, ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
+        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK].v, ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
+        const uint32_t nws = hc.cnt[parity][CLS_WAVE].v, nwm = hc.cnt[parity][CLS_WAVE_M].v, nwl = hc.cnt[parity][CLS_WAVE_L].v;
         if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kTB), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
-        if (nwav) {
-            const uint32_t g8 = (nwav + 7u) / 8u, g2 = (nwav + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes;
-            if (kWaveMax > 512u)
-                hipLaunchKernelGGL((build_level_wave<512u, kWaveMax, kWaveBigNodes, 2>), dim3(g2), dim3(64 * kWaveBigNodes), 0, sw3, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-            hipLaunchKernelGGL((build_level_wave<64u, (kWaveMax < 512u ? kWaveMax : 512u), 8, 4>), dim3(g8), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-            hipLaunchKernelGGL((build_level_wave<0u, 64u, 8, 8>), dim3(g8), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nwav, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-        }
+        if (nwl) hipLaunchKernelGGL((build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>), dim3((nwl + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes), dim3(64 * kWaveBigNodes), 0, sw3,
+                                    d_bn, ls.l[parity][CLS_WAVE_L], nwl, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (nwm) hipLaunchKernelGGL((build_level_wave<kWaveS, kWaveM, 8, 4>), dim3((nwm + 7u) / 8u), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE_M], nwm, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+        if (nws) hipLaunchKernelGGL((build_level_wave<0u, kWaveS, 8, 8>), dim3((nws + 7u) / 8u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nws, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 63u) / 64u), dim3(64), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (nsub) hipLaunchKernelGGL(build_subtree_tiny, dim3((nsub + 63u) / 64u), dim3(64), 0, ss, d_bn, ls.l[parity][CLS_SUB], nsub, d_px[cur], d_px[0], d_px[1], d_pool, d_ctrl);
         HIP_TRY(hipGetLastError());
@@ -1332,8 +1340,8 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         hc = *h_ctrl;
         const uint32_t total = hc.n_nodes.v;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        for (int c = 0; c < 5; c++) hc.cnt[parity][c].v = 0u;   // this level's lists are consumed: reset for level + 2
-        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, 5 * sizeof(Pad32), nullptr));           // stream-ordered, no host round trip
+        for (int c = 0; c < kClasses; c++) hc.cnt[parity][c].v = 0u;   // this level's lists are consumed: reset for level + 2
+        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, kClasses * sizeof(Pad32), nullptr));           // stream-ordered, no host round trip
         begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
