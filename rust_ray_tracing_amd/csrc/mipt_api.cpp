@@ -5,6 +5,7 @@
 #include "../../include/mipt.h"
 #include "pt_kernel.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -88,13 +89,15 @@ void free_scene(MiptScene *s) {
 }
 
 template <class T>
-int upload(void **dst, const std::vector<T> &src, size_t min_bytes = 16) {
-    size_t bytes = src.size() * sizeof(T);
+int upload(void **dst, const T *src, size_t count, size_t min_bytes = 16) {
+    size_t bytes = count * sizeof(T);
     size_t alloc = bytes < min_bytes ? min_bytes : bytes;
     HIP_TRY(hipMalloc(dst, alloc));
-    if (bytes) HIP_TRY(hipMemcpy(*dst, src.data(), bytes, hipMemcpyHostToDevice));
+    if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return MIPT_OK;
 }
+template <class T>
+int upload(void **dst, const std::vector<T> &src, size_t min_bytes = 16) { return upload(dst, src.data(), src.size(), min_bytes); }
 
 int ensure(void **p, size_t *have, size_t want_bytes) {
     if (*have >= want_bytes && *p) return MIPT_OK;
@@ -102,6 +105,49 @@ int ensure(void **p, size_t *have, size_t want_bytes) {
     HIP_TRY(hipMalloc(p, want_bytes));
     *have = want_bytes;
     return MIPT_OK;
+}
+
+// Host-side layout helpers.  The device layout of a 10 M-triangle scene is ~2 GB written once: std::vector would zero (touch) every
+// page on one thread before the fill loop writes it again, so the big arrays are malloc'ed (filled completely) or calloc'ed (pages
+// arrive zeroed from the kernel when a worker first touches them), and the fill loops run on up to 16 threads.
+template <class T> struct HostBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf() { free(p); }
+    bool alloc(size_t count, bool zeroed) {
+        free(p);
+        n = count;
+        p = (T *)(zeroed ? calloc(count ? count : 1, sizeof(T)) : malloc((count ? count : 1) * sizeof(T)));
+        return p != nullptr;
+    }
+    void swap(HostBuf &o) { T *tp = p; p = o.p; o.p = tp; size_t tn = n; n = o.n; o.n = tn; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *data() { return p; }
+    size_t size() const { return n; }
+};
+template <class T>
+int upload(void **dst, const HostBuf<T> &src, size_t min_bytes = 16) { return upload(dst, src.p, src.n, min_bytes); }
+template <class F> void parallel_for(size_t n, F body) {                 // body(begin, end) on disjoint ranges; results must not depend on the split
+    unsigned t = std::thread::hardware_concurrency();
+    if (t > 16u) t = 16u;
+    if (t < 2u || n < (size_t)1 << 16) { body((size_t)0, n); return; }
+    const size_t per = (n + t - 1) / t;
+    std::vector<std::thread> th;
+    size_t b = per;                                                       // [0, per) runs on the calling thread
+    try {
+        for (; b < n; b += per) { const size_t e = b + per < n ? b + per : n; th.emplace_back([&body, b, e]() { body(b, e); }); }
+    } catch (...) {                                                       // could not start a thread: the caller does the rest
+        body((size_t)0, per < n ? per : n);
+        for (auto &x : th) x.join();
+        body(b, n);
+        return;
+    }
+    body((size_t)0, per < n ? per : n);
+    for (auto &x : th) x.join();
 }
 
 } // namespace
@@ -186,18 +232,23 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     uint32_t n_slots = 0;
     if (mipt_internal_tri_slots(desc->nodes, desc->n_nodes, desc->n_tris, slot_of_tri.data(), &n_slots) != MIPT_OK)
         return fail(MIPT_ERR_BVH, "triangle slots: malformed BVH");
-    std::vector<float4> pairs((size_t)n_pairs * 4);
-    for (uint32_t k = 0; k < n_pairs; k++) {
-        for (uint32_t w = 0; w < 2; w++) {
-            const MiptNode &n = desc->nodes[2 * k + 1 + w];
-            const uint32_t a = n.num_tris > 0 ? slot_of_tri[n.first_tri_or_child] : (n.first_tri_or_child - 1u) / 2u;
-            float4 lo, hi;
-            lo.x = n.bounds_min.x; lo.y = n.bounds_min.y; lo.z = n.bounds_min.z; memcpy(&lo.w, &a, 4);
-            hi.x = n.bounds_max.x; hi.y = n.bounds_max.y; hi.z = n.bounds_max.z; memcpy(&hi.w, &n.num_tris, 4);
-            pairs[(size_t)k * 4 + w * 2 + 0] = lo;
-            pairs[(size_t)k * 4 + w * 2 + 1] = hi;
+    HostBuf<float4> pairs;                                                  // (+4: room for the pad record below)
+    if (!pairs.alloc((size_t)n_pairs * 4 + 4, false)) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
+    pairs.n = (size_t)n_pairs * 4;
+    for (int q = 0; q < 4; q++) pairs[(size_t)n_pairs * 4 + q] = make_float4(0, 0, 0, 0);
+    parallel_for(n_pairs, [&](size_t kb, size_t ke) {
+        for (size_t k = kb; k < ke; k++) {
+            for (uint32_t w = 0; w < 2; w++) {
+                const MiptNode &n = desc->nodes[2 * k + 1 + w];
+                const uint32_t a = n.num_tris > 0 ? slot_of_tri[n.first_tri_or_child] : (n.first_tri_or_child - 1u) / 2u;
+                float4 lo, hi;
+                lo.x = n.bounds_min.x; lo.y = n.bounds_min.y; lo.z = n.bounds_min.z; memcpy(&lo.w, &a, 4);
+                hi.x = n.bounds_max.x; hi.y = n.bounds_max.y; hi.z = n.bounds_max.z; memcpy(&hi.w, &n.num_tris, 4);
+                pairs[k * 4 + w * 2 + 0] = lo;
+                pairs[k * 4 + w * 2 + 1] = hi;
+            }
         }
-    }
+    });
     // ---- order of the pair records in HBM (mipt_internal_pair_order, bvh_build.cpp): the tree top breadth-first, below it every
     // pair in one 128-B line with the child pair of its larger inner child.  Topology, visit order and results are untouched; only
     // `a` of the inner children is renumbered.  (-DMIPT_PAIR_LAYOUT=0 keeps the reference's depth-first order, =1 the round-2 order.)
@@ -219,48 +270,64 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             *out = (n.first_tri_or_child - 1u) / 2u;
             return true;
         };
-        for (size_t j = 0; j < order.size(); j++) if (order[j] != 0xffffffffu) new_of[order[j]] = (uint32_t)j;
-        std::vector<float4> re(order.size() * 4, make_float4(0, 0, 0, 0));
-        for (size_t j = 0; j < order.size(); j++) {
-            if (order[j] == 0xffffffffu) continue;
-            for (int q = 0; q < 4; q++) re[j * 4 + q] = pairs[(size_t)order[j] * 4 + q];
-            for (uint32_t w = 0; w < 2; w++) {
-                uint32_t c;
-                if (child_pair(order[j], w, &c)) memcpy(&re[j * 4 + w * 2].w, &new_of[c], 4);
+        parallel_for(order.size(), [&](size_t jb, size_t je) {
+            for (size_t j = jb; j < je; j++) if (order[j] != 0xffffffffu) new_of[order[j]] = (uint32_t)j;      // every pair appears once: disjoint writes
+        });
+        HostBuf<float4> re;                                                 // pad records stay zero (calloc)
+        if (!re.alloc(order.size() * 4 + 4, true)) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
+        re.n = order.size() * 4;
+        parallel_for(order.size(), [&](size_t jb, size_t je) {
+            for (size_t j = jb; j < je; j++) {
+                if (order[j] == 0xffffffffu) continue;
+                for (int q = 0; q < 4; q++) re[j * 4 + q] = pairs[(size_t)order[j] * 4 + q];
+                for (uint32_t w = 0; w < 2; w++) {
+                    uint32_t c;
+                    if (child_pair(order[j], w, &c)) memcpy(&re[j * 4 + w * 2].w, &new_of[c], 4);
+                }
             }
-        }
+        });
         pairs.swap(re);
     }
 #endif
-    if ((pairs.size() / 4) & 1u) pairs.insert(pairs.end(), 4, make_float4(0, 0, 0, 0));   // the triangle stream behind it starts on a 128-B line
+    if ((pairs.size() / 4) & 1u) pairs.n += 4;                             // one zero pad record (allocated above): the triangle stream behind it starts on a 128-B line
     const uint32_t n_pair_records = (uint32_t)(pairs.size() / 4);
     // ---- triangles: 64-B-strided intersection stream + 64-B shading stream ----
     if (n_slots > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, "%u triangle slots exceed the 2^25 device-format limit", n_slots);
-    std::vector<float4> tri_pos((size_t)n_slots * mipt::kTriPosStride / 16 + 1, make_float4(0, 0, 0, 0));   // +1: the kernel's unconditional 4th float4 load
-    std::vector<float4> tri_attr((size_t)desc->n_tris * 4);
-    for (uint32_t i = 0; i < desc->n_tris; i++) {
-        const MiptTriangle &t = desc->tris[i];
-        if (t.material_id >= desc->n_materials)
-            return fail(MIPT_ERR_INVALID_ARG, "triangle %u has material_id %u >= n_materials %u", i, t.material_id, desc->n_materials);
-        const MiptVec3 v0 = t.vertices[0].position, v1 = t.vertices[1].position, v2 = t.vertices[2].position;
-        // edge_1 = v_2 - v_1, edge_2 = v_3 - v_1 (ray.rs:24-25): one rounded f32 subtraction each,
-        // the same value the reference recomputes per test (-ffp-contract=off; no fusing possible here).
-        const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
-        const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
-        const size_t q = (size_t)slot_of_tri[i] * (mipt::kTriPosStride / 16);
-        float idf;
-        memcpy(&idf, &i, 4);
-        tri_pos[q + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
-        tri_pos[q + 1] = make_float4(e1y, e1z, e2x, e2y);
-        tri_pos[q + 2] = make_float4(e2z, idf, 0.0f, 0.0f);
-        const MiptVec3 n0 = t.vertices[0].normal, n1 = t.vertices[1].normal, n2 = t.vertices[2].normal;
-        float mid;
-        memcpy(&mid, &t.material_id, 4);
-        tri_attr[(size_t)i * 4 + 0] = make_float4(n0.x, n0.y, n0.z, n1.x);
-        tri_attr[(size_t)i * 4 + 1] = make_float4(n1.y, n1.z, n2.x, n2.y);
-        tri_attr[(size_t)i * 4 + 2] = make_float4(n2.z, t.vertices[0].tex_coord_x, t.vertices[0].tex_coord_y, t.vertices[1].tex_coord_x);
-        tri_attr[(size_t)i * 4 + 3] = make_float4(t.vertices[1].tex_coord_y, t.vertices[2].tex_coord_x, t.vertices[2].tex_coord_y, mid);
-    }
+    HostBuf<float4> tri_pos, tri_attr;                                      // tri_pos: +1 for the kernel's unconditional 4th float4 load; unused slots / words stay zero
+    if (!tri_pos.alloc((size_t)n_slots * mipt::kTriPosStride / 16 + 1, true) || !tri_attr.alloc((size_t)desc->n_tris * 4, false))
+        return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
+    std::atomic<uint32_t> bad_tri{UINT32_MAX};
+    parallel_for(desc->n_tris, [&](size_t ib, size_t ie) {
+        for (size_t ii = ib; ii < ie; ii++) {
+            const uint32_t i = (uint32_t)ii;
+            const MiptTriangle &t = desc->tris[i];
+            if (t.material_id >= desc->n_materials) {                      // reported below: the lowest such triangle, as a sequential scan would
+                uint32_t cur = bad_tri.load();
+                while (i < cur && !bad_tri.compare_exchange_weak(cur, i)) {}
+                continue;
+            }
+            const MiptVec3 v0 = t.vertices[0].position, v1 = t.vertices[1].position, v2 = t.vertices[2].position;
+            // edge_1 = v_2 - v_1, edge_2 = v_3 - v_1 (ray.rs:24-25): one rounded f32 subtraction each,
+            // the same value the reference recomputes per test (-ffp-contract=off; no fusing possible here).
+            const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+            const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+            const size_t q = (size_t)slot_of_tri[i] * (mipt::kTriPosStride / 16);
+            float idf;
+            memcpy(&idf, &i, 4);
+            tri_pos[q + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
+            tri_pos[q + 1] = make_float4(e1y, e1z, e2x, e2y);
+            tri_pos[q + 2] = make_float4(e2z, idf, 0.0f, 0.0f);
+            const MiptVec3 n0 = t.vertices[0].normal, n1 = t.vertices[1].normal, n2 = t.vertices[2].normal;
+            float mid;
+            memcpy(&mid, &t.material_id, 4);
+            tri_attr[(size_t)i * 4 + 0] = make_float4(n0.x, n0.y, n0.z, n1.x);
+            tri_attr[(size_t)i * 4 + 1] = make_float4(n1.y, n1.z, n2.x, n2.y);
+            tri_attr[(size_t)i * 4 + 2] = make_float4(n2.z, t.vertices[0].tex_coord_x, t.vertices[0].tex_coord_y, t.vertices[1].tex_coord_x);
+            tri_attr[(size_t)i * 4 + 3] = make_float4(t.vertices[1].tex_coord_y, t.vertices[2].tex_coord_x, t.vertices[2].tex_coord_y, mid);
+        }
+    });
+    if (bad_tri.load() != UINT32_MAX)
+        return fail(MIPT_ERR_INVALID_ARG, "triangle %u has material_id %u >= n_materials %u", bad_tri.load(), desc->tris[bad_tri.load()].material_id, desc->n_materials);
     // ---- materials / textures ----
     struct TexDesc { uint32_t offset, width, height; };
     std::vector<TexDesc> texs(desc->n_textures);
