@@ -29,6 +29,14 @@ extern "C" {
 
 #define MIPT_ABI_VERSION 3
 
+/* libmipt.so is built with -fvisibility=hidden: exactly the functions declared here are exported
+ * (tests/test_abi.py compares `nm -D --defined-only` with this header). */
+#if defined(__GNUC__)
+#define MIPT_API __attribute__((visibility("default")))
+#else
+#define MIPT_API
+#endif
+
 /* ---- PODs, byte-identical to the reference's #[repr(C, align(16))] structs ---------- */
 typedef struct { float x, y, z; } MiptVec3;                 /* src/math/vec3.rs:55-59  (12 B) */
 
@@ -161,39 +169,39 @@ enum MiptStatus {
 /* Copies the scene to HBM of HIP device `device_id`, re-basing the BVH into 64-byte child-pair
  * records and splitting triangles into an intersection stream (36 B of payload at a 64-byte stride, so
  * a record never straddles a 128-byte line) and a 64-byte shading stream.  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
-int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out);
-void mipt_scene_destroy(MiptScene *scene);
+MIPT_API int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out);
+MIPT_API void mipt_scene_destroy(MiptScene *scene);
 
 /* Renders into HOST buffers and blocks until done.  Replaces cpu::render_scene
  * (cpu.rs:13-68) / gpu::render_scene_to_buffer (gpu.rs:14-94).
  *   hdr_rgb : width*height*3 f32, linear mean radiance per pixel (the value cpu.rs:60 holds
  *             before sRGB), row 0 = top; may be NULL.
  *   rgba8   : width*height*4 bytes, exactly the Vec<u8> cpu.rs:63-67 returns; may be NULL. */
-int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+MIPT_API int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
                 float *hdr_rgb, uint8_t *rgba8, MiptStats *stats);
 
 /* Same, into DEVICE buffers (e.g. torch tensors), launched on `hip_stream` (hipStream_t, may
  * be NULL = the null stream).  Blocks until the kernel has finished (stats are read back).
  * With tile sharding and MIPT_FLAG_PACKED, d_hdr_rgb holds mipt_packed_pixels() * 3 floats. */
-int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+MIPT_API int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
                        float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats);
 
 /* Tile-shard helpers (image tiles shard across GPUs; one RCCL all-gather of packed slices). */
-uint64_t mipt_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_world);
+MIPT_API uint64_t mipt_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_world);
 /* d_packed_all: tile_world slices of mipt_packed_pixels()*3 floats, rank-major (the layout an
  * all-gather produces); writes the full width*height*3 frame. */
-int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height,
+MIPT_API int mipt_unpack_tiles(const float *d_packed_all, uint32_t width, uint32_t height,
                       uint32_t tile_world, float *d_hdr_rgb, void *hip_stream);
 /* linear HDR -> sRGB -> RGBA8 epilogue on device (vec3.rs:80-90, 262-270; cpu.rs:61-64).
  * The radiance is first divided by `divisor` (the sample count for a summed buffer, cpu.rs:60;
  * 1 for a buffer that already holds the mean). */
-int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor,
+MIPT_API int mipt_tonemap_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor,
                         uint8_t *d_rgba8, void *hip_stream);
 
 /* The wgpu backend's post-process pass (pp_compute.wgsl:7-34): radiance / divisor, clamped to [0,1] (its accumulator is
  * rgba16unorm), linear_to_srgb, THEN aces_filmic, written as RGBA16 unorm (4 x u16 per pixel, alpha 65535) -- the pixel
  * format Renderer::render saves (renderer.rs:67-73, ColorType::Rgba16).  The CPU backend's epilogue is mipt_tonemap_device. */
-int mipt_postprocess_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint16_t *d_rgba16, void *hip_stream);
+MIPT_API int mipt_postprocess_device(const float *d_hdr_rgb, uint64_t n_pixels, float divisor, uint16_t *d_rgba16, void *hip_stream);
 
 /* ---- all GPUs of one node behind one call --------------------------------------------- */
 
@@ -222,33 +230,33 @@ typedef struct {
 
 /* device_ids: n_devices HIP device ordinals (NULL = 0..n_devices-1; n_devices 0 = every visible device).  Uploads one
  * replica per device (concurrently) and creates the communicators. */
-int  mipt_multi_create(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);
-void mipt_multi_destroy(MiptMulti *multi);
-int  mipt_multi_device_count(const MiptMulti *multi);
+MIPT_API int  mipt_multi_create(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);
+MIPT_API void mipt_multi_destroy(MiptMulti *multi);
+MIPT_API int  mipt_multi_device_count(const MiptMulti *multi);
 
 /* Renders one frame on all devices of `multi` into HOST buffers (either may be NULL) and blocks until done; same outputs
  * as mipt_render.  `opt` describes the whole frame: tile_rank / tile_world / sample_begin and the PACKED / SUM / ACCUM
  * flags must be 0 (the call owns the sharding); MIPT_FLAG_COUNT is honoured. */
-int  mipt_render_multi(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
+MIPT_API int  mipt_render_multi(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
                        float *hdr_rgb, uint8_t *rgba8, MiptMultiStats *stats);
 
 /* Same, but the frame stays in HBM: d_hdr_rgb (width*height*3 f32, required) and d_rgba8 (width*height*4 bytes, may be
  * NULL) are buffers in the memory of the ROOT device (mipt_multi_root_device(): device_ids[0]); the assemble kernels write
  * them directly and nothing crosses PCIe.  The multi-GPU counterpart of mipt_render_device. */
-int  mipt_render_multi_device(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
+MIPT_API int  mipt_render_multi_device(MiptMulti *multi, const MiptCamera *camera, const MiptOptions *opt, uint32_t mode,
                               float *d_hdr_rgb, uint8_t *d_rgba8, MiptMultiStats *stats);
 /* HIP ordinal of the device that gathers / reduces and holds the assembled frame, or a negative MiptStatus. */
-int  mipt_multi_root_device(const MiptMulti *multi);
+MIPT_API int  mipt_multi_root_device(const MiptMulti *multi);
 /* Trace-kernel stats of device `index` (0 .. mipt_multi_device_count()-1) in the last mipt_render_multi* call:
  * MiptMultiStats.total sums the counters, this is one device's share (what its one launch did). */
-int  mipt_multi_device_stats(const MiptMulti *multi, int index, MiptStats *out);
+MIPT_API int  mipt_multi_device_stats(const MiptMulti *multi, int index, MiptStats *out);
 
 /* ---- host-side restatements of the scene model that feeds the path ------------------- */
 
 /* BVH::build (src/bvh.rs:13-161): binned SAH, 8 bins; reorders `tris` in place exactly as
  * bvh.rs:99-108 does and emits the identical node array.  nodes_cap >= 2*n_tris-1.
  * threads: 0 = hardware concurrency. */
-int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out,
+MIPT_API int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out,
                    uint32_t nodes_cap, uint32_t *n_nodes_out, uint32_t threads);
 
 /* Scene::load for Wavefront OBJ + MTL (src/scene.rs:22-85, src/loader/obj.rs:16-436): parses the
@@ -256,38 +264,38 @@ int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out,
  * host arrays; mipt_obj_get fills a MiptSceneDesc that borrows them (valid until mipt_obj_free)
  * and, optionally, the material names in material-id order. */
 typedef struct MiptObj MiptObj;
-int  mipt_obj_load(const char *path, MiptObj **out);
-int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
-void mipt_obj_free(MiptObj *obj);
+MIPT_API int  mipt_obj_load(const char *path, MiptObj **out);
+MIPT_API int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
+MIPT_API void mipt_obj_free(MiptObj *obj);
 
 /* Texture::load (src/texture.rs:13-31): decodes an image file (PNG, JPEG, TGA, BMP or binary PPM, chosen by extension like
  * image::open), flips it vertically and expands to RGBA8; hash_out (may be NULL) receives the djb2 hash the loader
  * de-duplicates textures by (texture.rs:40-48).  desc_out borrows the image's pixels until mipt_texture_free. */
 typedef struct MiptImage MiptImage;
-int  mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out);
-void mipt_texture_free(MiptImage *img);
+MIPT_API int  mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out);
+MIPT_API void mipt_texture_free(MiptImage *img);
 
 /* The image output of Renderer::render (src/renderer.rs:66-83, image::save_buffer): writes width x height RGBA pixels,
  * top row first, as a PNG with 8 or 16 bits per sample (16-bit samples in host byte order; the reference saves
  * ColorType::Rgba16, and the bytes of its CPU arm are RGBA8 -- SURVEY T12).  Uncompressed deflate blocks. */
-int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba);
+MIPT_API int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba);
 
 /* The same build on the GPU (level-synchronous binned SAH with the partition's closed-form permutation); identical output
  * (sign of zero in a bound aside).  Uploads `tris`, downloads the reordered triangles and the nodes; build_ms_out (may be
  * NULL) receives the device time of the build itself without the transfers. */
-int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
+MIPT_API int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
                           uint32_t *n_nodes_out, int device_id, double *build_ms_out);
 
 /* Camera::update_view + Mat4f::look_at (src/scene.rs:181-194, src/math/mat4.rs:25-44). */
-int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg, MiptCamera *out);
+MIPT_API int mipt_camera_from_pose(const float position[3], float pitch_deg, float yaw_deg, MiptCamera *out);
 
 /* Material::default() (src/scene.rs:148-167). */
-void mipt_material_default(MiptMaterial *out);
+MIPT_API void mipt_material_default(MiptMaterial *out);
 
-const char *mipt_last_error(void);
-int mipt_abi_version(void);
+MIPT_API const char *mipt_last_error(void);
+MIPT_API int mipt_abi_version(void);
 /* number of HIP devices visible, or a negative MiptStatus */
-int mipt_device_count(void);
+MIPT_API int mipt_device_count(void);
 
 #ifdef __cplusplus
 }

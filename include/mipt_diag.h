@@ -16,19 +16,33 @@
 extern "C" {
 #endif
 
+#if defined(__GNUC__)
+#define MIPT_DIAG_API __attribute__((visibility("default")))
+#else
+#define MIPT_DIAG_API
+#endif
+
 /* host buffers in/out.  op: 0 cosf, 1 log10f, 2 powf(a,b), 3 a/b, 4 sqrt(a), 5 a*b, 6 a+b, 7 min, 8 max,
  *     9 rand_f32(seed=bits(a)), 10 rand_f32_nd(seed), 11 rand_in_unit_sphere(seed)[b], 12 srgb+quantise(a)
  *     (result as integer bits), 13 fract(a), 14 the per-ray-reciprocal division a/b (valid on its checked range),
  *     15 u8 -> f32/255 for the integer whose bits are a, 16 sinf, 17 expf, 18 logf,
  *     19 the kernel's log10f specialised to rand_f32's range {0} u [2^-32, 1], 20 its cosf specialised to [0, 6.2831855].
  * Returns 0, or -1 (bad argument) / -2 (HIP error); device buffers are released on every path. */
-int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out);
+MIPT_DIAG_API int mipt_debug_eval(int op, const float *a, const float *b, uint64_t n, float *out);
 
 /* ops 0, 1, 2 (with second argument y), 16, 17, 18, 19, 20 on the n consecutive binary32 bit patterns first_bits, first_bits+1, ...
  * (first_bits + n <= 2^32): the exhaustive sweeps of tests/test_gpu_libm.py. */
-int mipt_debug_eval_range(int op, uint32_t first_bits, uint64_t n, float y, float *out);
+MIPT_DIAG_API int mipt_debug_eval_range(int op, uint32_t first_bits, uint64_t n, float y, float *out);
 
-const char *mipt_diag_last_error(void);
+MIPT_DIAG_API const char *mipt_diag_last_error(void);
+
+/* The library-internal device-layout orders of libmipt.so (rust_ray_tracing_amd/csrc/bvh_build.cpp, hidden there), re-exported for
+ * tests/test_host_layout.py: order of the 64-byte pair records in HBM (order_out[j] = reference pair index of record j, 0xffffffff = a
+ * pad record), the number of breadth-first levels at its top, and the slot of every triangle's record in the intersection stream.
+ * nodes: the reference's 32-byte Node array (MiptNode). */
+MIPT_DIAG_API int mipt_internal_pair_order(const void *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);
+MIPT_DIAG_API uint32_t mipt_internal_pair_order_top(void);
+MIPT_DIAG_API int mipt_internal_tri_slots(const void *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);
 
 #ifdef __cplusplus
 }

@@ -108,7 +108,12 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is plumbing only
         pass
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    _lib = _bind(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+    return _lib
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
+    """argtypes / restype of every include/mipt.h entry point on a loaded library (the product or a build variant of it)."""
     vp, u32, u64, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
     lib.mipt_scene_create.argtypes = [C.POINTER(MiptSceneDesc), C.c_int, C.POINTER(vp)]
     lib.mipt_scene_create.restype = C.c_int
@@ -166,18 +171,39 @@ def load() -> C.CDLL:
     lib.mipt_multi_root_device.restype = C.c_int
     lib.mipt_multi_device_stats.argtypes = [vp, C.c_int, C.POINTER(MiptStats)]
     lib.mipt_multi_device_stats.restype = C.c_int
-    _lib = lib
+    return lib
+
+
+MULTITEST_LIB_PATH = os.path.join(_HERE, "libmipt_multitest.so")
+_multitest = None
+
+
+def load_multitest() -> C.CDLL:
+    """libmipt_multitest.so: the product's objects with mipt_multi.cpp compiled against the RCCL TEST DOUBLE of
+    tests/cpp/rccl_double/ (N logical ranks on one device).  Test infrastructure: lets the n > 1 code of mipt_render_multi run on
+    the one-GPU box.  Same C ABI (+ rccl_double_inject); its own error string and device state."""
+    global _multitest
+    if _multitest is not None:
+        return _multitest
+    load()
+    if not os.path.exists(MULTITEST_LIB_PATH):
+        raise ImportError(f"{MULTITEST_LIB_PATH} is missing: run __graft_entry__.build()")
+    lib = _bind(C.CDLL(MULTITEST_LIB_PATH))
+    lib.rccl_double_inject.argtypes = [C.c_int, C.c_int]
+    lib.rccl_double_inject.restype = C.c_longlong
+    _multitest = lib
     return lib
 
 
 DIAG_LIB_PATH = os.path.join(_HERE, "libmipt_diag.so")
-DIAG_EXPORTS = ["mipt_debug_eval", "mipt_debug_eval_range", "mipt_diag_last_error"]
+DIAG_EXPORTS = ["mipt_debug_eval", "mipt_debug_eval_range", "mipt_diag_last_error",
+                "mipt_internal_pair_order", "mipt_internal_pair_order_top", "mipt_internal_tri_slots"]
 _diag = None
 
 
 def load_diag() -> C.CDLL:
-    """libmipt_diag.so (include/mipt_diag.h): the device-arithmetic probe the GPU known-answer tests use.  Test
-    infrastructure; the product library exports none of it."""
+    """libmipt_diag.so (include/mipt_diag.h): the device-arithmetic probe the GPU known-answer tests use and the
+    re-exported layout functions (pair-record order, triangle slots).  Test infrastructure; the product library exports none of it."""
     global _diag
     if _diag is not None:
         return _diag
@@ -192,6 +218,13 @@ def load_diag() -> C.CDLL:
     lib.mipt_debug_eval_range.restype = C.c_int
     lib.mipt_diag_last_error.argtypes = []
     lib.mipt_diag_last_error.restype = C.c_char_p
+    u32p = C.POINTER(C.c_uint32)
+    lib.mipt_internal_pair_order.argtypes = [vp, C.c_uint32, vp, C.c_uint32, u32p]
+    lib.mipt_internal_pair_order.restype = C.c_int
+    lib.mipt_internal_pair_order_top.argtypes = []
+    lib.mipt_internal_pair_order_top.restype = C.c_uint32
+    lib.mipt_internal_tri_slots.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p]
+    lib.mipt_internal_tri_slots.restype = C.c_int
     _diag = lib
     return lib
 

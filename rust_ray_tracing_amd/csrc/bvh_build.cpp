@@ -18,6 +18,7 @@
 //    recurses left, right (bvh.rs:131-135), i.e. desc(X) = [A, B] ++ desc(A) ++ desc(B).  Subtrees
 //    are built into relative-indexed blocks and stitched in that order.
 #include "../../include/mipt.h"
+#include "mipt_internal.h"
 
 #include <atomic>
 #include <cfloat>
@@ -269,7 +270,7 @@ extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nod
 // ---- order of the device's 64-B pair records (pair k = {nodes[2k+1], nodes[2k+2]}; mipt_api.cpp builds the records) ----
 // The memory side moves whole 128-B lines and a traversal step gathers ONE 64-B record, so what matters is which record shares a
 // record's line.  Two zones:
-//   * the top MIPT_PAIR_LAYOUT_TOP levels, which every ray walks through and which stay resident in L1 / L2: breadth-first, level after
+//   * the top kPairLayoutTop levels, which every ray walks through and which stay resident in L1 / L2: breadth-first, level after
 //     level, every level starting on a line boundary -- one dense run of lines;
 //   * below them, where a line is cold whenever a ray reaches it: a pair shares its line with the child pair of its LARGER inner
 //     child (half area: SAH's own proxy for "the child the ray enters").  The step after a cold pair is then a hit more often than
@@ -279,15 +280,10 @@ extern "C" int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nod
 // (breadth-first with the two child pairs of a node in one line, which only moved hits from L2 to L1); the order was picked with
 // the replay model of tests/tools/layout_model.py (predicted 12.2 -> 10.0).  Topology, visit order and results are untouched.
 // order_out[j] = reference pair index of record j, or 0xffffffff for a pad record; *n_records_out = number of records.
-// Internal to the library (declared where it is used); exported for tests/test_host_layout.py.
-#ifndef MIPT_PAIR_LAYOUT
-#define MIPT_PAIR_LAYOUT 3          // 1 = the round-2 order (breadth-first couples) for A/B builds
-#endif
-#ifndef MIPT_PAIR_LAYOUT_TOP
-#define MIPT_PAIR_LAYOUT_TOP 12     // 8 ... 14 measure the same (2.005 - 2.03 G fills per frame); 16: 2.20, 18: 2.31, 0: 2.23
-#endif
-extern "C" uint32_t mipt_internal_pair_order_top(void) { return MIPT_PAIR_LAYOUT == 3 ? (uint32_t)MIPT_PAIR_LAYOUT_TOP : 0xffffffffu; }
-extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out) {
+// Internal to the library (mipt_internal.h); libmipt_diag.so re-exports it for tests/test_host_layout.py.
+constexpr uint32_t kPairLayoutTop = 12;   // 8 ... 14 measure the same (2.005 - 2.03 G fills per frame); 16: 2.20, 18: 2.31, 0: 2.23
+uint32_t mipt::pair_order_top() { return kPairLayoutTop; }
+int mipt::pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out) {
     if (!nodes || !order_out || !n_records_out || (n_nodes & 1u) == 0u) return MIPT_ERR_INVALID_ARG;
     try {
         const uint32_t n_pairs = (n_nodes - 1u) / 2u;
@@ -301,7 +297,6 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         };
         std::vector<uint32_t> level, couples, singles;
         if (n_pairs > 0) level.push_back(0u);
-#if MIPT_PAIR_LAYOUT == 3
         std::vector<uint8_t> taken(n_pairs, 0);
         std::vector<uint32_t> lone;
         auto half_area = [&](uint32_t node) -> double {
@@ -312,7 +307,7 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         uint32_t depth = 0;
         while (!level.empty()) {
             couples.clear(); singles.clear();
-            if (depth < (uint32_t)MIPT_PAIR_LAYOUT_TOP) {
+            if (depth < kPairLayoutTop) {
                 if (order.size() + level.size() + 1 > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;   // also bounds a malformed (shared-child) input
                 if (order.size() & 1u) order.push_back(0xffffffffu);
                 for (uint32_t k : level) order.push_back(k);
@@ -346,23 +341,6 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
         if (order.size() & 1u) order.push_back(0xffffffffu);
         if (order.size() + lone.size() > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;
         for (uint32_t k : lone) order.push_back(k);      // level order: sibling pairs that are both free are neighbours (and mostly line mates)
-#else
-        while (!level.empty()) {
-            if (order.size() & 1u) order.push_back(0xffffffffu);            // every level starts on a line boundary
-            if (order.size() + level.size() > (size_t)cap) return MIPT_ERR_SCENE_LIMIT;   // also bounds a malformed (shared-child) input
-            for (uint32_t k : level) order.push_back(k);
-            couples.clear(); singles.clear();
-            for (uint32_t k : level) {
-                uint32_t ca = 0, cb = 0;
-                const bool ha = child_pair(k, 0, &ca), hb = child_pair(k, 1, &cb);
-                if (ha && hb) { couples.push_back(ca); couples.push_back(cb); }     // an even count in front keeps couples line-aligned
-                else if (ha) singles.push_back(ca);
-                else if (hb) singles.push_back(cb);
-            }
-            level = couples;
-            level.insert(level.end(), singles.begin(), singles.end());
-        }
-#endif
         if (order.size() > cap) return MIPT_ERR_SCENE_LIMIT;
         for (size_t j = 0; j < order.size(); j++) order_out[j] = order[j];
         *n_records_out = (uint32_t)order.size();
@@ -380,17 +358,13 @@ extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes,
 // pair, whose triangles are neighbours in the reference order: bvh.rs:99-115 partitions a node's range in place), then all remaining
 // triangles follow in the reference order.  The record carries the triangle's reference index, which is what a hit reports.
 // Measured with the parent+child pair lines: 10.55 -> 10.04 line fills per ray (profiles/r3_layout_ab.csv).
-// The caller has validated the nodes (leaves partition [0, n_tris)).  Exported for tests/test_host_layout.py.
-#ifndef MIPT_TRI_LAYOUT
-#define MIPT_TRI_LAYOUT 1           // 0 = reference order, 2 = reference order + a pad slot wherever a double would straddle a line (A/B builds)
-#endif
-extern "C" int mipt_internal_tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out) {
+// The caller has validated the nodes (leaves partition [0, n_tris)).
+int mipt::tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out) {
     if (!nodes || !slot_out || !n_slots_out || (n_nodes & 1u) == 0u) return MIPT_ERR_INVALID_ARG;
     try {
         const uint32_t n_pairs = (n_nodes - 1u) / 2u;
         uint32_t next = 0;
         auto in_range = [&](const MiptNode &n) { return n.num_tris == 0u || (uint64_t)n.first_tri_or_child + n.num_tris <= n_tris; };
-#if MIPT_TRI_LAYOUT == 1
         std::vector<uint8_t> placed(n_tris, 0);
         for (uint32_t k = 0; k < n_pairs; k++) {
             const MiptNode &l = nodes[2 * k + 1], &r = nodes[2 * k + 2];
@@ -408,23 +382,6 @@ extern "C" int mipt_internal_tri_slots(const MiptNode *nodes, uint32_t n_nodes, 
         }
         for (uint32_t i = 0; i < n_tris; i++)
             if (!placed[i]) slot_out[i] = next++;
-#elif MIPT_TRI_LAYOUT == 2
-        std::vector<uint8_t> starts_double(n_tris, 0);
-        for (uint32_t k = 0; k < n_pairs; k++) {
-            const MiptNode &l = nodes[2 * k + 1], &r = nodes[2 * k + 2];
-            if (!in_range(l) || !in_range(r)) return MIPT_ERR_BVH;
-            if (l.num_tris == 1u && r.num_tris == 1u && r.first_tri_or_child == l.first_tri_or_child + 1u) starts_double[l.first_tri_or_child] = 1;
-            if (l.num_tris == 2u) starts_double[l.first_tri_or_child] = 1;
-            if (r.num_tris == 2u) starts_double[r.first_tri_or_child] = 1;
-        }
-        for (uint32_t i = 0; i < n_tris; i++) {
-            if (starts_double[i] && (next & 1u)) next++;
-            slot_out[i] = next++;
-        }
-#else
-        (void)n_pairs; (void)in_range;
-        for (uint32_t i = 0; i < n_tris; i++) slot_out[i] = next++;
-#endif
         *n_slots_out = next;
         return MIPT_OK;
     } catch (const std::exception &) {

@@ -27,7 +27,7 @@
 #include <cstring>
 #include <vector>
 
-void mipt_internal_set_error(const char *msg);
+#include "mipt_internal.h"
 
 namespace {
 
@@ -35,21 +35,12 @@ constexpr int kT = 256;
 constexpr float F32_MAX = FLT_MAX;
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kSubFlag = 0x80000000u;   // BNode::left = kSubFlag | pool index: the node's whole subtree lives in the pool (build_subtree_tiny)
-#ifndef MIPT_BVH_BIG
-#define MIPT_BVH_BIG 8192
-#endif
-#ifndef MIPT_BVH_CHUNK
-#define MIPT_BVH_CHUNK 8192
-#endif
-#ifndef MIPT_BVH_WAVEMAX
-#define MIPT_BVH_WAVEMAX 2048
-#endif
-constexpr uint32_t kBig = MIPT_BVH_BIG;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
-constexpr uint32_t kChunk = MIPT_BVH_CHUNK;
+constexpr uint32_t kBig = 8192;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
+constexpr uint32_t kChunk = 8192;
 constexpr uint32_t kSub = 8;               // nodes this small: ONE thread finishes the whole subtree (build_subtree_tiny)
 constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
-constexpr uint32_t kWaveMax = MIPT_BVH_WAVEMAX;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
+constexpr uint32_t kWaveMax = 2048;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
 enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3, CLS_SUB = 4, CLS_WAVE_M = 5, CLS_WAVE_L = 6, kClasses = 7 };   // CLS_WAVE: 17..64, _M: 65..512, _L: 513..kWaveMax triangles
 constexpr uint32_t kWaveS = 64u, kWaveM = 512u;
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
@@ -1283,9 +1274,6 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
-#ifdef MIPT_BVH_ONE_STREAM                                  // diagnosis: every kernel alone on the GPU (tools/bvh_trace.sh)
-    { hipStream_t all[] = {sw, sw2, sw3, st, sg, ss}; for (hipStream_t x : all) (void)hipStreamDestroy(x); sw = sw2 = sw3 = st = sg = ss = sb; }
-#endif
     HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));

@@ -4,6 +4,7 @@
 // without a HIP device the entry points return MIPT_ERR_HIP.
 #include "../../include/mipt.h"
 #include "pt_kernel.h"
+#include "mipt_internal.h"
 
 #include <atomic>
 #include <cmath>
@@ -51,8 +52,6 @@ int fail(int code, const char *fmt, ...) {
 } // namespace
 
 void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
-extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);   // bvh_build.cpp
-extern "C" int mipt_internal_tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);      // bvh_build.cpp
 
 struct MiptScene {
     int device = 0;
@@ -227,10 +226,10 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     }
     for (uint32_t k = 0; k < n_pairs; k++)
         if (!pair_seen[k]) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * k + 1, 2 * k + 2);
-    // ---- slots of the intersection stream (mipt_internal_tri_slots, bvh_build.cpp): where triangle i's 64-B record sits ----
+    // ---- slots of the intersection stream (mipt::tri_slots, bvh_build.cpp): where triangle i's 64-B record sits ----
     std::vector<uint32_t> slot_of_tri(desc->n_tris);
     uint32_t n_slots = 0;
-    if (mipt_internal_tri_slots(desc->nodes, desc->n_nodes, desc->n_tris, slot_of_tri.data(), &n_slots) != MIPT_OK)
+    if (mipt::tri_slots(desc->nodes, desc->n_nodes, desc->n_tris, slot_of_tri.data(), &n_slots) != MIPT_OK)
         return fail(MIPT_ERR_BVH, "triangle slots: malformed BVH");
     HostBuf<float4> pairs;                                                  // (+4: room for the pad record below)
     if (!pairs.alloc((size_t)n_pairs * 4 + 4, false)) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
@@ -249,18 +248,17 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
             }
         }
     });
-    // ---- order of the pair records in HBM (mipt_internal_pair_order, bvh_build.cpp): the tree top breadth-first, below it every
+    // ---- order of the pair records in HBM (mipt::pair_order, bvh_build.cpp): the tree top breadth-first, below it every
     // pair in one 128-B line with the child pair of its larger inner child.  Topology, visit order and results are untouched; only
-    // `a` of the inner children is renumbered.  (-DMIPT_PAIR_LAYOUT=0 keeps the reference's depth-first order, =1 the round-2 order.)
+    // `a` of the inner children is renumbered.
     std::vector<uint32_t> new_of(n_pairs);                                  // reference pair index -> record index in HBM
     for (uint32_t k = 0; k < n_pairs; k++) new_of[k] = k;
-#if !defined(MIPT_PAIR_LAYOUT) || MIPT_PAIR_LAYOUT != 0
     if (n_pairs > 0) {
         std::vector<uint32_t> order(2 * (size_t)n_pairs + 2);               // record index -> reference pair index (0xffffffff = pad; at most one pad per level)
         uint32_t n_records = 0;
         {
             const uint32_t cap = order.size() < (size_t)mipt::kMaxPairs ? (uint32_t)order.size() : mipt::kMaxPairs;
-            const int rc = mipt_internal_pair_order(desc->nodes, desc->n_nodes, order.data(), cap, &n_records);   // bvh_build.cpp
+            const int rc = mipt::pair_order(desc->nodes, desc->n_nodes, order.data(), cap, &n_records);   // bvh_build.cpp
             if (rc != MIPT_OK) return fail(rc, "pair records (with line padding) exceed the 2^24 device-format limit or the order buffer");
         }
         order.resize(n_records);
@@ -288,7 +286,6 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
         });
         pairs.swap(re);
     }
-#endif
     if ((pairs.size() / 4) & 1u) pairs.n += 4;                             // one zero pad record (allocated above): the triangle stream behind it starts on a 128-B line
     const uint32_t n_pair_records = (uint32_t)(pairs.size() / 4);
     // ---- triangles: 64-B-strided intersection stream + 64-B shading stream ----
@@ -465,10 +462,12 @@ static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene
     catch (const std::bad_alloc &) { return fail(MIPT_ERR_INVALID_ARG, "out of host memory"); }                        \
     catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, "internal error: %s", e.what()); }
 int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out) { MIPT_NO_THROW(scene_create_impl(desc, device_id, out)) }
+} // extern "C"
 // internal (mipt_multi.cpp): one host-side layout build, n uploads
-int mipt_scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
+int mipt::scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
     MIPT_NO_THROW(scene_create_many(desc, device_ids, n_dev, outs))
 }
+extern "C" {
 
 void mipt_scene_destroy(MiptScene *scene) { free_scene(scene); }
 
@@ -502,8 +501,9 @@ static int validate_options(const MiptOptions *opt) {
 
 // `pack_single`: honour MIPT_FLAG_PACKED also at tile_world == 1 (mipt_render_multi with one device keeps the same
 // gather + unpack path as with eight); through the public entry PACKED at world 1 means full-frame, as documented.
-int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
-                            float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single) {
+} // extern "C"
+int mipt::render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
+                             float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single) {
     if (!scene || !camera) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_device: null scene or camera");
     int rc = validate_options(opt);
     if (rc) return rc;
@@ -535,11 +535,6 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     pr.samples_f = (float)opt->samples;                       // cpu.rs:60
     pr.cull_scale = 1.0f + opt->cull_margin;
     pr.service_num = 3; pr.service_den = 8; pr.reverse_tiles = 0;   // service pass when >= 3/8 of the live lanes wait for one (tools/sweep_service.py)
-#ifdef MIPT_TUNING   // experiment knobs exist only in a `make TUNING=1` build (tools/README.md); the product reads no environment
-    if (const char *e = getenv("MIPT_REVERSE_TILES")) pr.reverse_tiles = atoi(e) ? 1u : 0u;
-    if (const char *e = getenv("MIPT_SERVICE_NUM")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_num = (uint32_t)v; }
-    if (const char *e = getenv("MIPT_SERVICE_DEN")) { int v = atoi(e); if (v >= 1 && v <= 64) pr.service_den = (uint32_t)v; }
-#endif
     for (int c = 0; c < 3; c++)
         for (int r = 0; r < 3; r++) pr.cam[c * 3 + r] = camera->look_at[c][r];
     pr.cam[9] = camera->position.x; pr.cam[10] = camera->position.y; pr.cam[11] = camera->position.z;
@@ -563,11 +558,6 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     // (world 2 / 4 / 8) spends most of its time in the latency-bound tail and is 2 - 8 % slower with it: period 1 there
     pr.leaf_period = (pr.total_work >= 4ull * (unsigned long long)scene->n_cu * (unsigned long long)occ * mipt::kBlockThreads) ? 4u : 1u;
     pr.leaf_den = 4u;
-#ifdef MIPT_TUNING
-    if (const char *env = getenv("MIPT_BLOCKS_PER_CU")) { int v = atoi(env); if (v >= 1 && v <= 8) bpc = v < occ ? v : occ; }
-    if (const char *env = getenv("MIPT_LEAF_PERIOD")) { int v = atoi(env); if (v >= 1 && v <= 64) pr.leaf_period = (uint32_t)v; }
-    if (const char *env = getenv("MIPT_LEAF_DEN")) { int v = atoi(env); if (v >= 0 && v <= 64) pr.leaf_den = (uint32_t)v; }
-#endif
     long long grid = (long long)scene->n_cu * bpc;
     const long long need_blocks = (long long)((pr.total_work + mipt::kBlockThreads - 1) / mipt::kBlockThreads);
     if (grid > need_blocks) grid = need_blocks;
@@ -621,9 +611,11 @@ int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const Mi
     return MIPT_OK;
 }
 
+extern "C" {
+
 int mipt_render_device(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,
                        float *d_hdr_rgb, uint8_t *d_rgba8, void *hip_stream, MiptStats *stats) {
-    return mipt_render_device_impl(scene, camera, opt, d_hdr_rgb, d_rgba8, hip_stream, stats, false);
+    return mipt::render_device_impl(scene, camera, opt, d_hdr_rgb, d_rgba8, hip_stream, stats, false);
 }
 
 int mipt_render(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt,

@@ -1,0 +1,26 @@
+// mipt_internal.h -- functions shared between the translation units of libmipt.so.  None of them is exported: the library is built
+// with -fvisibility=hidden and only the MIPT_API declarations of include/mipt.h leave it.  (Host C++ only: no HIP types here, so the
+// CPU sanitizer builds of tests/cpp/ can include it.)  The test library libmipt_diag.so links the same objects and re-exports the
+// layout functions under their old mipt_internal_* names (tests/cpp/layout_hooks.cpp).
+#pragma once
+#include "../../include/mipt.h"
+
+void mipt_internal_set_error(const char *msg);          // sets the calling thread's mipt_last_error() text (mipt_api.cpp)
+
+namespace mipt {
+
+// ---- device-layout orders (bvh_build.cpp; the device-resident scene setup of scene_device.hip reproduces both bit for bit) ----
+// Order of the 64-B pair records in HBM: order_out[j] = reference pair index of record j, 0xffffffff = pad record.
+int pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);
+uint32_t pair_order_top();                               // number of breadth-first levels at the top of that order
+// Slot of every triangle's 64-B record in the intersection stream.
+int tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);
+
+// ---- mipt_api.cpp, used by mipt_multi.cpp ----
+// One host-side layout build, n uploads (replicas for mipt_multi_create).
+int scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs);
+// mipt_render_device with `pack_single`: honour MIPT_FLAG_PACKED also at tile_world == 1.
+int render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt, float *d_hdr_rgb, uint8_t *d_rgba8,
+                       void *hip_stream, MiptStats *stats, bool pack_single);
+
+} // namespace mipt

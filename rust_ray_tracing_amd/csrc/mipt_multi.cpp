@@ -13,6 +13,7 @@
 // frame); the reduce of a 4096^2 frame is 201 MB per GPU through RCCL's ring/tree.  Either is noise next to the trace.
 #include "../../include/mipt.h"
 #include "pt_kernel.h"
+#include "mipt_internal.h"
 
 #include <rccl/rccl.h>
 
@@ -23,10 +24,6 @@
 #include <thread>
 #include <vector>
 
-void mipt_internal_set_error(const char *msg);
-extern "C" int mipt_scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs);
-extern "C" int mipt_render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt, float *d_hdr_rgb,
-                                       uint8_t *d_rgba8, void *hip_stream, MiptStats *stats, bool pack_single);
 
 struct MiptMulti {
     int n = 0;
@@ -48,6 +45,15 @@ struct MiptMulti {
 
 namespace {
 
+// libmipt_multitest.so (make multitest; test infrastructure, never the product) compiles this file against the RCCL test double of
+// tests/cpp/rccl_double/, whose header defines MIPT_RCCL_DOUBLE: there a HIP device may carry several logical ranks, so that the
+// n > 1 code below runs on the one-GPU test box.  Real RCCL refuses a device listed twice, and so does the product.
+#ifdef MIPT_RCCL_DOUBLE
+constexpr bool kLogicalRanks = true;
+#else
+constexpr bool kLogicalRanks = false;
+#endif
+
 int fail(int code, const std::string &msg) {
     mipt_internal_set_error(msg.c_str());
     return code;
@@ -68,6 +74,16 @@ int grow(void **p, size_t *have, size_t want_bytes) {
     if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
     M_HIP(hipMalloc(p, want_bytes));
     *have = want_bytes;
+    return MIPT_OK;
+}
+
+int root_buffer_check(const void *p, int root_device, const char *name) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) (void)hipGetLastError();         // an unregistered host pointer is reported as an error: clear it
+    if (e != hipSuccess || a.type != hipMemoryTypeDevice || a.device != root_device)
+        return fail(MIPT_ERR_INVALID_ARG, std::string("mipt_render_multi_device: ") + name + " is not device memory of the root device " + std::to_string(root_device));
     return MIPT_OK;
 }
 
@@ -97,14 +113,14 @@ int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices,
     const int visible = mipt_device_count();
     if (visible < 0) return visible;
     if (n_devices == 0) n_devices = visible;                     // 0 = every visible device
-    if (n_devices < 1 || n_devices > visible || n_devices > 64)
+    if (n_devices < 1 || (!kLogicalRanks && n_devices > visible) || n_devices > 64)
         return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_create: n_devices " + std::to_string(n_devices) + " but " + std::to_string(visible) + " HIP device(s) visible");
     MiptMulti *m = new MiptMulti();
     m->n = n_devices;
     for (int i = 0; i < n_devices; i++) {
         const int d = device_ids ? device_ids[i] : i;
         if (d < 0 || d >= visible) { destroy(m); return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_create: bad device id " + std::to_string(d)); }
-        for (int j = 0; j < i; j++)
+        for (int j = 0; j < i && !kLogicalRanks; j++)
             if (m->devices[j] == d) { destroy(m); return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_create: device listed twice"); }
         m->devices.push_back(d);
     }
@@ -115,7 +131,7 @@ int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices,
     m->last.assign(n_devices, MiptStats{});
     // scene replicas: the device layout is built once on the host, the uploads run concurrently (one host thread per device)
     {
-        const int rc = mipt_scene_create_replicas(desc, m->devices.data(), n_devices, m->scenes.data());
+        const int rc = mipt::scene_create_replicas(desc, m->devices.data(), n_devices, m->scenes.data());
         if (rc) { const std::string e = mipt_last_error(); destroy(m); return fail(rc, e); }
     }
     for (int i = 0; i < n_devices; i++) {
@@ -147,6 +163,11 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
                 MiptMultiStats *stats, bool device_out) {
     if (!m || !camera || !opt) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_multi: null argument");
     if (device_out && !hdr_rgb) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_multi_device: d_hdr_rgb == NULL");
+    if (device_out) {                                     // a host pointer or another device's buffer would fault inside the assemble kernels
+        int rc = root_buffer_check(hdr_rgb, m->devices[0], "d_hdr_rgb");
+        if (rc == MIPT_OK && rgba8) rc = root_buffer_check(rgba8, m->devices[0], "d_rgba8");
+        if (rc) return rc;
+    }
     if (mode > MIPT_MULTI_SAMPLES) return fail(MIPT_ERR_INVALID_ARG, "mipt_render_multi: unknown mode");
     if (opt->tile_rank || opt->tile_world > 1 || opt->sample_begin > 1 ||
         (opt->flags & (MIPT_FLAG_PACKED | MIPT_FLAG_SUM | MIPT_FLAG_ACCUM)))
@@ -222,7 +243,7 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
                     if (e != hipSuccess) { rcs[i] = MIPT_ERR_HIP; errs[i] = hipGetErrorString(e); }
                     return;
                 }
-                rcs[i] = mipt_render_device_impl(m->scenes[i], camera, &opts[i], m->d_part[i], nullptr, (void *)m->streams[i], &st[i], true);
+                rcs[i] = mipt::render_device_impl(m->scenes[i], camera, &opts[i], m->d_part[i], nullptr, (void *)m->streams[i], &st[i], true);
                 if (rcs[i]) errs[i] = mipt_last_error();
         };
         // a std::thread constructor that throws (EAGAIN) must not unwind past joinable threads: join what was started

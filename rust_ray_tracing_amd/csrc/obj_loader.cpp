@@ -26,7 +26,7 @@
 #include <string>
 #include <vector>
 
-void mipt_internal_set_error(const char *msg);   // mipt_api.cpp: feeds mipt_last_error()
+#include "mipt_internal.h"   // mipt_internal_set_error (mipt_api.cpp) feeds mipt_last_error()
 namespace mipt_png {
 bool decode(const std::string &path, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgba, std::string *err);
 bool write_rgba(const std::string &path, uint32_t w, uint32_t h, int bits, const void *rgba, std::string *err);

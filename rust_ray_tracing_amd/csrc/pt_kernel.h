@@ -84,10 +84,7 @@ struct DevParams {
 constexpr int kStackLds = 16;               // per-lane traversal-stack entries held in LDS
 constexpr int kStackOvf = 48;               // further entries spilled to HBM (rarely touched)
 constexpr int kWavesPerBlock = 4;
-#ifndef MIPT_TRI_POS_STRIDE
-#define MIPT_TRI_POS_STRIDE 64
-#endif
-constexpr uint32_t kTriPosStride = MIPT_TRI_POS_STRIDE;   // bytes per record of the intersection stream: 48 packed, 64 = never straddles a 128-B line
+constexpr uint32_t kTriPosStride = 64;   // bytes per record of the intersection stream: 48 packed, 64 = never straddles a 128-B line
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
 constexpr uint32_t kMaxTris = 1u << 25;     // stack-entry encoding: 25-bit triangle index
 constexpr uint32_t kMaxPairs = 1u << 24;    // 24-bit pair index in the child-ref form

@@ -14,8 +14,7 @@
 
 static std::string g_err;
 void mipt_internal_set_error(const char *m) { g_err = m ? m : ""; }
-extern "C" int mipt_internal_pair_order(const MiptNode *nodes, uint32_t n_nodes, uint32_t *order_out, uint32_t cap, uint32_t *n_records_out);
-extern "C" int mipt_internal_tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);
+#include "../../rust_ray_tracing_amd/csrc/mipt_internal.h"   // mipt::pair_order / mipt::tri_slots (bvh_build.cpp)
 extern "C" void mipt_material_default(MiptMaterial *m) { memset(m, 0, sizeof *m); m->base_color = {0.8f, 0.8f, 0.8f}; m->base_color_tex_id = m->emission_tex_id = UINT32_MAX; }
 namespace mipt_png { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
 namespace mipt_jpeg { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
@@ -78,7 +77,7 @@ int main(int argc, char **argv) {
         {   // the device record order over the same tree (bvh_build.cpp): a permutation of the pairs plus line pads
             std::vector<uint32_t> order((size_t)cnt + 2);
             uint32_t n_rec = 0;
-            if (mipt_internal_pair_order(nodes.data(), cnt, order.data(), (uint32_t)order.size(), &n_rec) != MIPT_OK) return 7;
+            if (mipt::pair_order(nodes.data(), cnt, order.data(), (uint32_t)order.size(), &n_rec) != MIPT_OK) return 7;
             std::vector<char> seen((cnt - 1) / 2, 0);
             for (uint32_t j = 0; j < n_rec; j++) {
                 if (order[j] == 0xffffffffu) continue;
@@ -89,7 +88,7 @@ int main(int argc, char **argv) {
             // the triangle slots of the intersection stream: a permutation, every leaf's triangles consecutive
             std::vector<uint32_t> slot((size_t)n);
             uint32_t n_slots = 0;
-            if (mipt_internal_tri_slots(nodes.data(), cnt, (uint32_t)n, slot.data(), &n_slots) != MIPT_OK || n_slots != (uint32_t)n) return 10;
+            if (mipt::tri_slots(nodes.data(), cnt, (uint32_t)n, slot.data(), &n_slots) != MIPT_OK || n_slots != (uint32_t)n) return 10;
             std::vector<char> used((size_t)n, 0);
             for (uint32_t sidx : slot) { if (sidx >= (uint32_t)n || used[sidx]) return 11; used[sidx] = 1; }
             for (uint32_t j = 0; j < cnt; j++)

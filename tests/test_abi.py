@@ -26,6 +26,37 @@ def test_every_declared_symbol_is_exported(rrt):
     assert lib.mipt_abi_version() == 3
 
 
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_exports_are_exactly_the_header(rrt):
+    """libmipt.so is built with -fvisibility=hidden + a version script: its dynamic symbol table is include/mipt.h, no more
+    (no internal helper, no C++ symbol, no test hook) and no less."""
+    from rust_ray_tracing_amd import _lib as L
+    assert _dynamic_symbols(L.LIB_PATH) == header_symbols()
+
+
+def test_multi_rank_test_build_is_not_the_product(rrt):
+    """libmipt_multitest.so (RCCL test double, logical ranks on one device) is test infrastructure: the product links the real
+    librccl, carries nothing of the double and refuses a device listed twice (GPU: tests/test_gpu_multi.py)."""
+    import subprocess
+    from rust_ray_tracing_amd import _lib as L
+    deps = subprocess.run(["ldd", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in deps
+    strings = subprocess.run(["strings", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl double" not in strings and "rccl_double" not in strings
+    assert os.path.exists(L.MULTITEST_LIB_PATH)
+    tdeps = subprocess.run(["ldd", L.MULTITEST_LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in tdeps and "libamdhip64" in tdeps
+    assert _dynamic_symbols(L.MULTITEST_LIB_PATH) == sorted(header_symbols() + ["rccl_double_inject"])
+    # the only thing that differs between the two builds of mipt_multi.cpp is keyed on the double's header
+    src = open(os.path.join(ROOT, "rust_ray_tracing_amd", "csrc", "mipt_multi.cpp")).read()
+    assert src.count("#ifdef MIPT_RCCL_DOUBLE") == 1 and "#include <rccl/rccl.h>" in src
+
+
 def test_diag_probe_is_a_separate_library(rrt):
     """The device-arithmetic probe (include/mipt_diag.h) lives in libmipt_diag.so; the product exports none of it."""
     import subprocess
@@ -35,9 +66,10 @@ def test_diag_probe_is_a_separate_library(rrt):
     assert sorted(L.DIAG_EXPORTS) == syms
     for s in syms:
         assert hasattr(diag, s)
+    assert _dynamic_symbols(L.DIAG_LIB_PATH) == syms
     out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
-    assert "debug_eval" not in out and "mipt_diag" not in out
-    # and the product reads no tuning knob from the environment (those exist only in a `make TUNING=1` build)
+    assert "debug_eval" not in out and "mipt_diag" not in out and "mipt_internal" not in out
+    # and the product reads no tuning knob from the environment (the knobs live in tools/experiments/ab_layout_macros_and_tuning_knobs.patch)
     strings = subprocess.run(["strings", L.LIB_PATH], capture_output=True, text=True).stdout
     for knob in ("MIPT_LDS_TOP", "MIPT_REVERSE_TILES", "MIPT_SERVICE_NUM", "MIPT_SERVICE_DEN", "MIPT_BLOCKS_PER_CU", "MIPT_LEAF_PERIOD", "MIPT_LEAF_DEN"):
         assert knob not in strings, knob

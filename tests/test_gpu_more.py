@@ -688,11 +688,10 @@ def test_touched_lines_equal_the_oracles_visit_log(rrt, orc):
     log = log[log != 0xFFFFFFFF]
     kind, idx = log >> 30, (log & 0x3FFFFFFF).astype(np.int64)
     # device layout: pair records, then (line-aligned) the triangle stream
-    mlib = rrt.load()
+    mlib = rrt.load_diag()                      # the library-internal layout functions, re-exported by libmipt_diag.so
     n_pairs = (len(sc.bvh_nodes) - 1) // 2
     order = np.zeros(2 * n_pairs + 2, dtype=np.uint32)
     n_rec = C.c_uint32(0)
-    mlib.mipt_internal_pair_order.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     assert mlib.mipt_internal_pair_order(sc.bvh_nodes.ctypes.data, len(sc.bvh_nodes), order.ctypes.data, order.size, C.byref(n_rec)) == 0
     order = order[: n_rec.value]
     rec = np.zeros(n_pairs, dtype=np.int64)
@@ -700,7 +699,6 @@ def test_touched_lines_equal_the_oracles_visit_log(rrt, orc):
     pair_lines = (n_rec.value + 1) // 2
     slot = np.zeros(len(sc.tris), dtype=np.uint32)
     n_slots = C.c_uint32(0)
-    mlib.mipt_internal_tri_slots.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     assert mlib.mipt_internal_tri_slots(sc.bvh_nodes.ctypes.data, len(sc.bvh_nodes), len(sc.tris), slot.ctypes.data, C.byref(n_slots)) == 0
     geom = set((rec[idx[kind <= 1]] // 2).tolist()) | set((pair_lines + slot[idx[kind == 2]].astype(np.int64) // 2).tolist())
     attr = set((idx[kind == 3] // 2).tolist())

@@ -1,4 +1,4 @@
-"""CPU: the order of the device's pair records (csrc/bvh_build.cpp mipt_internal_pair_order, used by mipt_scene_create) --
+"""CPU: the order of the device's pair records (csrc/bvh_build.cpp mipt::pair_order, used by mipt_scene_create; reached through libmipt_diag.so) --
 the top levels breadth-first, below them every pair in one 128-B line with the child pair of its larger inner child.
 Topology is untouched: the function only permutes record positions."""
 import ctypes as C
@@ -8,10 +8,7 @@ import pytest
 
 
 def _order(rrt, nodes):
-    lib = rrt.load()
-    fn = lib.mipt_internal_pair_order
-    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
-    fn.restype = C.c_int
+    fn = rrt.load_diag().mipt_internal_pair_order           # libmipt_diag.so re-exports the library-internal function
     n_pairs = (len(nodes) - 1) // 2
     out = np.zeros(2 * n_pairs + 2, dtype=np.uint32)
     n = C.c_uint32(0)
@@ -20,9 +17,7 @@ def _order(rrt, nodes):
 
 
 def _top(rrt):
-    fn = rrt.load().mipt_internal_pair_order_top
-    fn.restype = C.c_uint32
-    return int(fn())
+    return int(rrt.load_diag().mipt_internal_pair_order_top())
 
 
 def _half_area(n):
@@ -147,9 +142,7 @@ def test_shared_child_bvh_is_refused_quickly(rrt):
     for w in range(2):
         nodes[2 * (n_pairs - 1) + 1 + w]["num_tris"] = 1
     lib = rrt.load()
-    fn = lib.mipt_internal_pair_order
-    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
-    fn.restype = C.c_int
+    fn = rrt.load_diag().mipt_internal_pair_order           # libmipt_diag.so re-exports the library-internal function
     out = np.zeros(2 * n_pairs + 2, dtype=np.uint32)
     n = C.c_uint32(0)
     t0 = time.time()
@@ -187,9 +180,7 @@ def test_shared_child_bvh_is_refused_quickly(rrt):
 
 
 def _slots(rrt, nodes, n_tris):
-    fn = rrt.load().mipt_internal_tri_slots
-    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
-    fn.restype = C.c_int
+    fn = rrt.load_diag().mipt_internal_tri_slots
     out = np.zeros(n_tris, dtype=np.uint32)
     n = C.c_uint32(0)
     assert fn(nodes.ctypes.data, len(nodes), n_tris, out.ctypes.data, C.byref(n)) == 0

@@ -103,10 +103,7 @@ print(f"pairs {n_pairs}: LL {np.mean(leafL & leafR):.3f}  LI {np.mean(leafL ^ le
 
 def pair_order_product():
     """record index -> pair (0xffffffff = pad): the product's breadth-first couples order (bvh_build.cpp)."""
-    lib = rrt.load()
-    fn = lib.mipt_internal_pair_order
-    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
-    fn.restype = C.c_int
+    fn = rrt.load_diag().mipt_internal_pair_order
     out = np.zeros(2 * n_pairs + 2, dtype=np.uint32)
     n = C.c_uint32(0)
     assert fn(nodes.ctypes.data, n_nodes, out.ctypes.data, out.size, C.byref(n)) == 0
