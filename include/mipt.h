@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 3
+#define MIPT_ABI_VERSION 4
 
 /* libmipt.so is built with -fvisibility=hidden: exactly the functions declared here are exported
  * (tests/test_abi.py compares `nm -D --defined-only` with this header). */
@@ -167,10 +167,38 @@ enum MiptStatus {
 /* ---- the seam ----------------------------------------------------------------------- */
 
 /* Copies the scene to HBM of HIP device `device_id`, re-basing the BVH into 64-byte child-pair
- * records and splitting triangles into an intersection stream (36 B of payload at a 64-byte stride, so
- * a record never straddles a 128-byte line) and a 64-byte shading stream.  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
+ * records and splitting triangles into an intersection stream (40 B of payload -- v0, e1, e2 and the triangle's
+ * reference index -- at a 64-byte stride, so a record never straddles a 128-byte line) and a 64-byte shading stream.  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
 MIPT_API int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out);
 MIPT_API void mipt_scene_destroy(MiptScene *scene);
+
+/* The same scene from its TRIANGLES alone -- desc->nodes / n_nodes are ignored (may be NULL / 0): BVH::build (bvh.rs:13-161) runs on
+ * the GPU and everything after the one host -> device copy of the triangle array stays in HBM: the node array in the reference's
+ * order, the re-based pair records, both triangle streams.  The tree, the triangle order and every byte of the device layout are
+ * identical to mipt_bvh_build + mipt_scene_create (sign of zero in a bound aside); only the time differs (10 M triangles: ~0.15 s
+ * against ~10 s of host build or 1.3 s of mipt_bvh_build_device + mipt_scene_create).  The triangle array is read in the caller's
+ * order and not modified; mipt_scene_get_bvh returns what BVH::build would have left in the host's Scene. */
+MIPT_API int mipt_scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out);
+
+/* The tree of a scene made by mipt_scene_create_from_triangles: nodes_out receives the node array (BVH::build's output, nodes_cap >=
+ * 2 * n_tris - 1 is always enough), tri_order_out (n_tris entries, may be NULL) the permutation bvh.rs:99-108 applied to the
+ * triangles: reordered[t] = original[tri_order_out[t]].  MIPT_ERR_INVALID_ARG for a scene made from host-built nodes. */
+MIPT_API int mipt_scene_get_bvh(MiptScene *scene, MiptNode *nodes_out, uint32_t nodes_cap, uint32_t *n_nodes_out, uint32_t *tri_order_out);
+
+/* What a scene holds and what it took to get it there (host clock, ms; build_ms: HIP events). */
+typedef struct {
+    uint32_t n_tris, n_nodes;
+    uint32_t n_pair_records;      /* 64-byte pair records incl. line padding */
+    uint32_t max_leaf;            /* largest leaf (triangles) */
+    uint64_t geometry_bytes;      /* pair records + both triangle streams in HBM */
+    uint32_t built_on_device;     /* 1: mipt_scene_create_from_triangles */
+    uint32_t replica_of_device;   /* for a replica made by device-to-device copy: the source device ordinal + 1; else 0 */
+    double   upload_ms;           /* host -> device copies (geometry + materials + textures) */
+    double   build_ms;            /* device BVH build, kernels only; 0 for host-built nodes */
+    double   layout_ms;           /* device layout: host re-layout (mipt_scene_create) or layout kernels */
+    double   total_ms;            /* the whole create call */
+} MiptSceneInfo;
+MIPT_API int mipt_scene_info(const MiptScene *scene, MiptSceneInfo *out);
 
 /* Renders into HOST buffers and blocks until done.  Replaces cpu::render_scene
  * (cpu.rs:13-68) / gpu::render_scene_to_buffer (gpu.rs:14-94).
@@ -228,9 +256,13 @@ typedef struct {
     uint32_t  n_devices, reserved;
 } MiptMultiStats;
 
-/* device_ids: n_devices HIP device ordinals (NULL = 0..n_devices-1; n_devices 0 = every visible device).  Uploads one
- * replica per device (concurrently) and creates the communicators. */
+/* device_ids: n_devices HIP device ordinals (NULL = 0..n_devices-1; n_devices 0 = every visible device).  The scene crosses PCIe
+ * ONCE, to device_ids[0]; the other replicas are device-to-device copies over xGMI.  Creates the communicators. */
 MIPT_API int  mipt_multi_create(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);
+/* Same from the triangles alone (mipt_scene_create_from_triangles on device_ids[0], then the xGMI replicas). */
+MIPT_API int  mipt_multi_create_from_triangles(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);
+/* The replica on device `index` (0 .. mipt_multi_device_count()-1), owned by `multi`: for mipt_scene_info / mipt_scene_get_bvh. */
+MIPT_API MiptScene *mipt_multi_scene(MiptMulti *multi, int index);
 MIPT_API void mipt_multi_destroy(MiptMulti *multi);
 MIPT_API int  mipt_multi_device_count(const MiptMulti *multi);
 

@@ -44,6 +44,13 @@ MIPT_DIAG_API int mipt_internal_pair_order(const void *nodes, uint32_t n_nodes, 
 MIPT_DIAG_API uint32_t mipt_internal_pair_order_top(void);
 MIPT_DIAG_API int mipt_internal_tri_slots(const void *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);
 
+/* The device layout behind a MiptScene handle of libmipt.so (tests/cpp/scene_hooks.hip), for comparing the layout the GPU kernels
+ * build (mipt_scene_create_from_triangles) with the host-built one (mipt_scene_create): sizes in bytes of [pair records | intersection
+ * stream] and of the attribute stream; a copy of either (which = 0 / 1) to the host; an order-dependent 64-bit fingerprint of each. */
+MIPT_DIAG_API int mipt_diag_scene_sizes(const void *scene, uint64_t out[2]);
+MIPT_DIAG_API int mipt_diag_scene_read(const void *scene, int which, void *dst, uint64_t bytes);
+MIPT_DIAG_API int mipt_diag_scene_hash(const void *scene, uint64_t out[2]);
+
 #ifdef __cplusplus
 }
 #endif

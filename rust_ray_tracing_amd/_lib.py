@@ -69,6 +69,15 @@ class MiptStats(C.Structure):
         return d
 
 
+class MiptSceneInfo(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("n_pair_records", C.c_uint32), ("max_leaf", C.c_uint32),
+                ("geometry_bytes", C.c_uint64), ("built_on_device", C.c_uint32), ("replica_of_device", C.c_uint32),
+                ("upload_ms", C.c_double), ("build_ms", C.c_double), ("layout_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class MiptMultiStats(C.Structure):
     _fields_ = [("total", MiptStats), ("collective_ms", C.c_double), ("wall_ms", C.c_double),
                 ("device_kernel_ms", C.c_double * 8), ("n_devices", C.c_uint32), ("reserved", C.c_uint32)]
@@ -89,6 +98,7 @@ EXPORTS = [
     "mipt_texture_load", "mipt_texture_free", "mipt_image_save_png",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_render_multi",
     "mipt_render_multi_device", "mipt_multi_root_device", "mipt_multi_device_stats",
+    "mipt_scene_create_from_triangles", "mipt_scene_get_bvh", "mipt_scene_info", "mipt_multi_create_from_triangles", "mipt_multi_scene",
 ]
 
 _lib = None
@@ -171,6 +181,16 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.mipt_multi_root_device.restype = C.c_int
     lib.mipt_multi_device_stats.argtypes = [vp, C.c_int, C.POINTER(MiptStats)]
     lib.mipt_multi_device_stats.restype = C.c_int
+    lib.mipt_scene_create_from_triangles.argtypes = [C.POINTER(MiptSceneDesc), C.c_int, C.POINTER(vp)]
+    lib.mipt_scene_create_from_triangles.restype = C.c_int
+    lib.mipt_scene_get_bvh.argtypes = [vp, vp, u32, C.POINTER(u32), vp]
+    lib.mipt_scene_get_bvh.restype = C.c_int
+    lib.mipt_scene_info.argtypes = [vp, C.POINTER(MiptSceneInfo)]
+    lib.mipt_scene_info.restype = C.c_int
+    lib.mipt_multi_create_from_triangles.argtypes = [C.POINTER(MiptSceneDesc), vp, C.c_int, C.POINTER(vp)]
+    lib.mipt_multi_create_from_triangles.restype = C.c_int
+    lib.mipt_multi_scene.argtypes = [vp, C.c_int]
+    lib.mipt_multi_scene.restype = vp
     return lib
 
 
@@ -197,7 +217,8 @@ def load_multitest() -> C.CDLL:
 
 DIAG_LIB_PATH = os.path.join(_HERE, "libmipt_diag.so")
 DIAG_EXPORTS = ["mipt_debug_eval", "mipt_debug_eval_range", "mipt_diag_last_error",
-                "mipt_internal_pair_order", "mipt_internal_pair_order_top", "mipt_internal_tri_slots"]
+                "mipt_internal_pair_order", "mipt_internal_pair_order_top", "mipt_internal_tri_slots",
+                "mipt_diag_scene_sizes", "mipt_diag_scene_read", "mipt_diag_scene_hash"]
 _diag = None
 
 
@@ -225,6 +246,12 @@ def load_diag() -> C.CDLL:
     lib.mipt_internal_pair_order_top.restype = C.c_uint32
     lib.mipt_internal_tri_slots.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p]
     lib.mipt_internal_tri_slots.restype = C.c_int
+    lib.mipt_diag_scene_sizes.argtypes = [vp, C.POINTER(C.c_uint64 * 2)]
+    lib.mipt_diag_scene_sizes.restype = C.c_int
+    lib.mipt_diag_scene_read.argtypes = [vp, C.c_int, vp, C.c_uint64]
+    lib.mipt_diag_scene_read.restype = C.c_int
+    lib.mipt_diag_scene_hash.argtypes = [vp, C.POINTER(C.c_uint64 * 2)]
+    lib.mipt_diag_scene_hash.restype = C.c_int
     _diag = lib
     return lib
 

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "mipt_internal.h"
+#include "mipt_scene.h"
 
 namespace {
 
@@ -1187,12 +1188,15 @@ __global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, const PoolNode *__
         }
     }
 }
-__global__ void gather_tris(const MiptTriangle *src, const Proxy *px, uint32_t n, MiptTriangle *dst) {
+__global__ void extract_order(const Proxy *px, uint32_t n, uint32_t *order) {        // reordered[t] = original[order[t]]
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) order[i] = px[i].idx;
+}
+__global__ void gather_tris(const MiptTriangle *src, const uint32_t *order, uint32_t n, MiptTriangle *dst) {
     // 112-B records as 7 x 16 B; one thread per (triangle, 16-B piece)
     const unsigned long long total = (unsigned long long)n * 7ull;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t t = (uint32_t)(i / 7ull), piece = (uint32_t)(i % 7ull);
-        reinterpret_cast<float4 *>(dst)[(unsigned long long)t * 7ull + piece] = reinterpret_cast<const float4 *>(src)[(unsigned long long)px[t].idx * 7ull + piece];
+        reinterpret_cast<float4 *>(dst)[(unsigned long long)t * 7ull + piece] = reinterpret_cast<const float4 *>(src)[(unsigned long long)order[t] * 7ull + piece];
     }
 }
 
@@ -1206,13 +1210,16 @@ int fail(int code, const char *what, hipError_t e) {
 
 } // namespace
 
-extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
-                                     uint32_t *n_nodes_out, int device_id, double *build_ms_out) {
-    if (!tris || !nodes_out || n_tris == 0 || nodes_cap == 0) { mipt_internal_set_error("mipt_bvh_build_device: bad argument (empty scene: the reference panics)"); return MIPT_ERR_INVALID_ARG; }
-    MiptTriangle *d_tris = nullptr, *d_out = nullptr;
+// The build proper: triangles already in HBM (`d_tris`, original order), results stay in HBM -- the node array in the reference's
+// order and the permutation BVH::build applied to the triangles (reordered[t] = original[tri_order[t]]).  Both are hipMalloc'ed here
+// and owned by the caller.  Used by mipt_bvh_build_device (below) and by the device-resident scene setup (scene_device.hip).
+int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int device_id, ResidentBvh *res) {
+    if (!d_tris || !res || n_tris == 0) { mipt_internal_set_error("mipt_bvh_build_device: bad argument (empty scene: the reference panics)"); return MIPT_ERR_INVALID_ARG; }
+    *res = ResidentBvh{};
     Proxy *d_px[2] = {nullptr, nullptr};
     BNode *d_bn = nullptr;
     MiptNode *d_nodes = nullptr;
+    uint32_t *d_order = nullptr;
     PoolNode *d_pool = nullptr;
     uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
     Ctrl *d_ctrl = nullptr, *h_ctrl = nullptr;
@@ -1223,26 +1230,20 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     hipStream_t sb = nullptr, sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
         hipStream_t all[] = {sb, sw, sw2, sw3, st, sg, ss};
-        for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) {
-            bool seen = false;
-            for (size_t j = 0; j < i; j++) seen = seen || all[j] == all[i];
-            if (all[i] && !seen) (void)hipStreamDestroy(all[i]);
-        }
-        void *p[] = {d_tris, d_out, d_px[0], d_px[1], d_bn, d_nodes, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
+        for (hipStream_t x : all) if (x) (void)hipStreamDestroy(x);
+        void *p[] = {d_px[0], d_px[1], d_bn, d_nodes, d_order, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (h_ctrl) (void)hipHostFree(h_ctrl);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
     HIP_TRY(hipSetDevice(device_id));
-    const size_t nb = (size_t)n_tris * sizeof(MiptTriangle);
     const uint32_t max_nodes = 2u * n_tris;
-    HIP_TRY(hipMalloc((void **)&d_tris, nb));
-    HIP_TRY(hipMalloc((void **)&d_out, nb));
     HIP_TRY(hipMalloc((void **)&d_px[0], (size_t)n_tris * sizeof(Proxy)));
     HIP_TRY(hipMalloc((void **)&d_px[1], (size_t)n_tris * sizeof(Proxy)));
     HIP_TRY(hipMalloc((void **)&d_bn, (size_t)max_nodes * sizeof(BNode)));
     HIP_TRY(hipMalloc((void **)&d_nodes, (size_t)max_nodes * sizeof(MiptNode)));
+    HIP_TRY(hipMalloc((void **)&d_order, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_pool, (size_t)max_nodes * sizeof(PoolNode)));
     HIP_TRY(hipMalloc((void **)&d_hp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
@@ -1274,7 +1275,6 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
-    HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
     const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
     Ctrl hc;
@@ -1337,7 +1337,6 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
     const uint32_t n_nodes = n_bn + hc.sub_nodes.v;
     lvl_begin.push_back(n_bn);
     if (n_nodes > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-    if (n_nodes > nodes_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: nodes_cap too small"); return MIPT_ERR_INVALID_ARG; }
     for (int l = (int)lvl_begin.size() - 2; l >= 0; l--) {
         const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
         hipLaunchKernelGGL(sizes_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
@@ -1347,15 +1346,53 @@ extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNo
         hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
     }
     hipLaunchKernelGGL(emit_nodes, dim3(2048), dim3(256), 0, nullptr, d_bn, n_bn, d_pool, d_nodes);
-    hipLaunchKernelGGL(gather_tris, dim3(4096), dim3(256), 0, nullptr, d_tris, d_px[cur], n_tris, d_out);
+    hipLaunchKernelGGL(extract_order, dim3(2048), dim3(256), 0, nullptr, d_px[cur], n_tris, d_order);
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    res->d_nodes = d_nodes; res->n_nodes = n_nodes; res->d_tri_order = d_order; res->build_ms = ms;
+    res->levels = (uint32_t)lvl_begin.size();
+    d_nodes = nullptr; d_order = nullptr;                   // the caller's now
+    cleanup();
+    return MIPT_OK;
+}
+
+// The C ABI entry: host arrays in, host arrays out (reorders `tris` in place like bvh.rs:105).
+extern "C" int mipt_bvh_build_device(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes_out, uint32_t nodes_cap,
+                                     uint32_t *n_nodes_out, int device_id, double *build_ms_out) {
+    if (!tris || !nodes_out || n_tris == 0 || nodes_cap == 0) { mipt_internal_set_error("mipt_bvh_build_device: bad argument (empty scene: the reference panics)"); return MIPT_ERR_INVALID_ARG; }
+    MiptTriangle *d_tris = nullptr, *d_out = nullptr;
+    mipt::ResidentBvh r;
+    auto cleanup = [&]() {
+        if (d_tris) (void)hipFree(d_tris);
+        if (d_out) (void)hipFree(d_out);
+        if (r.d_nodes) (void)hipFree(r.d_nodes);
+        if (r.d_tri_order) (void)hipFree(r.d_tri_order);
+    };
+    HIP_TRY(hipSetDevice(device_id));
+    const size_t nb = (size_t)n_tris * sizeof(MiptTriangle);
+    HIP_TRY(hipMalloc((void **)&d_tris, nb));
+    HIP_TRY(hipMalloc((void **)&d_out, nb));
+    HIP_TRY(hipMemcpy(d_tris, tris, nb, hipMemcpyHostToDevice));
+    const int rc = mipt::bvh_build_resident(d_tris, n_tris, device_id, &r);
+    if (rc != MIPT_OK) { cleanup(); return rc; }
+    if (r.n_nodes > nodes_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: nodes_cap too small"); return MIPT_ERR_INVALID_ARG; }
+    hipEvent_t g0 = nullptr, g1 = nullptr;                  // the 112-byte gather belongs to the build (bvh.rs:105 swaps the triangles themselves)
+    HIP_TRY(hipEventCreate(&g0));
+    if (hipEventCreate(&g1) != hipSuccess) { (void)hipEventDestroy(g0); cleanup(); mipt_internal_set_error("mipt_bvh_build_device: hipEventCreate failed"); return MIPT_ERR_HIP; }
+    (void)hipEventRecord(g0, nullptr);
+    hipLaunchKernelGGL(gather_tris, dim3(4096), dim3(256), 0, nullptr, d_tris, r.d_tri_order, n_tris, d_out);
+    (void)hipEventRecord(g1, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    float gms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&gms, g0, g1);
+    (void)hipEventDestroy(g0); (void)hipEventDestroy(g1);
+    HIP_TRY(e);
     HIP_TRY(hipMemcpy(tris, d_out, nb, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(nodes_out, d_nodes, (size_t)n_nodes * sizeof(MiptNode), hipMemcpyDeviceToHost));
-    if (n_nodes_out) *n_nodes_out = n_nodes;
-    if (build_ms_out) *build_ms_out = ms;
+    HIP_TRY(hipMemcpy(nodes_out, r.d_nodes, (size_t)r.n_nodes * sizeof(MiptNode), hipMemcpyDeviceToHost));
+    if (n_nodes_out) *n_nodes_out = r.n_nodes;
+    if (build_ms_out) *build_ms_out = r.build_ms + gms;
     cleanup();
     return MIPT_OK;
 }

@@ -5,8 +5,10 @@
 #include "../../include/mipt.h"
 #include "pt_kernel.h"
 #include "mipt_internal.h"
+#include "mipt_scene.h"
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,7 +28,8 @@ static_assert(sizeof(MiptNode) == 32 && offsetof(MiptNode, first_tri_or_child) =
 static_assert(sizeof(MiptMaterial) == 80 && offsetof(MiptMaterial, ior) == 28 && offsetof(MiptMaterial, emission) == 32 &&
                   offsetof(MiptMaterial, roughness) == 44 && offsetof(MiptMaterial, base_color_tex_id) == 56, "Material");
 static_assert(sizeof(MiptCamera) == 80 && offsetof(MiptCamera, position) == 64, "UniformCamera");
-static_assert(sizeof(MiptStats) == 8 + 22 * 8 && sizeof(MiptOptions) == 64, "ABI v3 struct sizes (tests/test_abi.py, rust_ray_tracing_amd/_lib.py)");
+static_assert(sizeof(MiptStats) == 8 + 22 * 8 && sizeof(MiptOptions) == 64, "ABI struct sizes (tests/test_abi.py, rust_ray_tracing_amd/_lib.py)");
+static_assert(sizeof(MiptSceneInfo) == 64, "MiptSceneInfo");
 static_assert(sizeof(mipt::DevMaterial) == 64 && sizeof(mipt::DevMaterialFull) == 128, "device records");
 
 namespace {
@@ -53,32 +56,10 @@ int fail(int code, const char *fmt, ...) {
 
 void mipt_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 
-struct MiptScene {
-    int device = 0;
-    mipt::DevScene dev{};
-    void *d_geom = nullptr, *d_tri_attr = nullptr, *d_mats = nullptr, *d_mats_full = nullptr,
-         *d_texels = nullptr;
-    // workspace
-    mipt::DevStats *d_stats = nullptr;
-    uint32_t *d_ovf = nullptr;
-    size_t ovf_waves = 0;
-    uint32_t *d_touched = nullptr;          // MIPT_FLAG_TOUCHED: line bitmap, allocated on first use
-    size_t n_tris = 0;
-    float *d_hdr = nullptr;
-    size_t hdr_floats = 0;
-    uint8_t *d_rgba = nullptr;
-    size_t rgba_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int n_cu = 0;
-    uint32_t max_leaf = 0;
-};
-
-namespace {
-
-void free_scene(MiptScene *s) {
+void mipt::free_scene(MiptScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels,
+    void *ptrs[] = {s->d_geom, s->d_tri_attr, s->d_mats, s->d_mats_full, s->d_texels, s->d_nodes, s->d_tri_order,
                     s->d_stats, s->d_ovf, s->d_hdr, s->d_rgba, s->d_touched};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -86,6 +67,12 @@ void free_scene(MiptScene *s) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
 }
+
+namespace {
+
+using mipt::free_scene;
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <class T>
 int upload(void **dst, const T *src, size_t count, size_t min_bytes = 16) {
@@ -151,6 +138,131 @@ template <class F> void parallel_for(size_t n, F body) {                 // body
 
 } // namespace
 
+// ---- pieces shared with the device-resident setup (scene_device.hip) ----
+int mipt::build_material_tables(const MiptSceneDesc *desc, MaterialTables *out) {
+    struct TexDesc { uint32_t offset, width, height; };
+    if (!desc->materials || desc->n_materials == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no materials");
+    if (desc->n_textures && !desc->textures) return fail(MIPT_ERR_INVALID_ARG, "n_textures > 0 but textures == NULL");
+    std::vector<TexDesc> texs(desc->n_textures);
+    uint64_t n_texels = 0;
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        const MiptTexture &t = desc->textures[i];
+        if (!t.rgba8 || t.width == 0 || t.height == 0) return fail(MIPT_ERR_INVALID_ARG, "texture %u is empty", i);
+        if (n_texels + (uint64_t)t.width * t.height > 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "texture pool exceeds 2^32 texels");
+        texs[i] = {(uint32_t)n_texels, t.width, t.height};
+        n_texels += (uint64_t)t.width * t.height;
+    }
+    out->mats.assign(desc->n_materials, mipt::DevMaterial{});
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const MiptMaterial &m = desc->materials[i];
+        if ((m.base_color_tex_id != UINT32_MAX && m.base_color_tex_id >= desc->n_textures) ||
+            (m.emission_tex_id != UINT32_MAX && m.emission_tex_id >= desc->n_textures))
+            return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
+        mipt::DevMaterial d{};
+        d.base[0] = m.base_color.x; d.base[1] = m.base_color.y; d.base[2] = m.base_color.z;
+        d.emis[0] = m.emission.x; d.emis[1] = m.emission.y; d.emis[2] = m.emission.z;
+        if (m.base_color_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.base_color_tex_id]; d.base_off = t.offset; d.base_w = t.width; d.base_h = t.height; }
+        if (m.emission_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.emission_tex_id]; d.emis_off = t.offset; d.emis_w = t.width; d.emis_h = t.height; }
+        out->mats[i] = d;
+    }
+    out->mats_full.assign(desc->n_materials, mipt::DevMaterialFull{});
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const MiptMaterial &m = desc->materials[i];
+        mipt::DevMaterialFull f{};
+        f.base[0] = m.base_color.x; f.base[1] = m.base_color.y; f.base[2] = m.base_color.z; f.transmission = m.transmission;
+        f.emission[0] = m.emission.x; f.emission[1] = m.emission.y; f.emission[2] = m.emission.z; f.ior = m.ior;
+        f.roughness = m.roughness; f.metallic = m.metallic; f.transparency = m.transparency;
+        const uint32_t ids[6] = {m.base_color_tex_id, m.transparency_tex_id, m.roughness_tex_id, m.metallic_tex_id, m.emission_tex_id, m.normal_tex_id};
+        for (int k = 0; k < 6; k++) {
+            if (ids[k] == UINT32_MAX) continue;
+            if (ids[k] >= desc->n_textures) return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
+            f.tex[k][0] = texs[ids[k]].offset; f.tex[k][1] = texs[ids[k]].width; f.tex[k][2] = texs[ids[k]].height;
+        }
+        out->mats_full[i] = f;
+    }
+    out->texels.resize((size_t)n_texels);
+    for (uint32_t i = 0; i < desc->n_textures; i++)
+        memcpy(out->texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
+    return MIPT_OK;
+}
+
+int mipt::upload_material_tables(MiptScene *s, const MaterialTables &t) {
+    int rc;
+    if ((rc = upload(&s->d_mats, t.mats, 64)) || (rc = upload(&s->d_mats_full, t.mats_full, 128)) || (rc = upload(&s->d_texels, t.texels, 16))) return rc;
+    s->mats_bytes = t.mats.size() * sizeof(mipt::DevMaterial) < 64 ? 64 : t.mats.size() * sizeof(mipt::DevMaterial);
+    s->mats_full_bytes = t.mats_full.size() * sizeof(mipt::DevMaterialFull) < 128 ? 128 : t.mats_full.size() * sizeof(mipt::DevMaterialFull);
+    s->texel_bytes = t.texels.size() * 4 < 16 ? 16 : t.texels.size() * 4;
+    s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
+    s->dev.mats_full = (const mipt::DevMaterialFull *)s->d_mats_full;
+    s->dev.texels = (const uint32_t *)s->d_texels;
+    return MIPT_OK;
+}
+
+int mipt::scene_finish_workspace(MiptScene *s) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, s->device);
+    if (e != hipSuccess) return fail(MIPT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    s->n_cu = prop.multiProcessorCount;
+    if ((e = hipMalloc((void **)&s->d_stats, sizeof(mipt::DevStats))) != hipSuccess ||
+        (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess)
+        return fail(MIPT_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e));
+    return MIPT_OK;
+}
+
+// Replica by device-to-device copy.  hipMemcpyPeer needs no peer mapping; with one enabled (tried, failure ignored) the copy engines
+// move the data directly over the xGMI link between the two GPUs instead of staging it.
+int mipt::scene_clone_to(const MiptScene *src, int device, MiptScene **out) {
+    *out = nullptr;
+    const double t0 = now_ms();
+    HIP_TRY(hipSetDevice(device));
+    if (device != src->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+            if (pe != hipSuccess) (void)hipGetLastError();          // hipErrorPeerAccessAlreadyEnabled included
+        }
+    }
+    MiptScene *s = new (std::nothrow) MiptScene();
+    if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
+    s->device = device;
+    s->dev = src->dev;
+    s->max_leaf = src->max_leaf; s->n_tris = src->n_tris; s->n_nodes = src->n_nodes; s->info = src->info;
+    s->geom_alloc = src->geom_alloc; s->attr_bytes = src->attr_bytes; s->mats_bytes = src->mats_bytes;
+    s->mats_full_bytes = src->mats_full_bytes; s->texel_bytes = src->texel_bytes;
+    struct Part { void **dst; const void *from; size_t alloc, copy; };
+    const Part parts[] = {{&s->d_geom, src->d_geom, src->geom_alloc, (size_t)src->dev.geom_bytes},
+                          {&s->d_tri_attr, src->d_tri_attr, src->attr_bytes < 16 ? 16 : src->attr_bytes, src->attr_bytes},
+                          {&s->d_mats, src->d_mats, src->mats_bytes, src->mats_bytes},
+                          {&s->d_mats_full, src->d_mats_full, src->mats_full_bytes, src->mats_full_bytes},
+                          {&s->d_texels, src->d_texels, src->texel_bytes, src->texel_bytes},
+                          {(void **)&s->d_nodes, src->d_nodes, (size_t)src->n_nodes * sizeof(MiptNode), src->d_nodes ? (size_t)src->n_nodes * sizeof(MiptNode) : 0},
+                          {(void **)&s->d_tri_order, src->d_tri_order, src->n_tris * 4, src->d_tri_order ? src->n_tris * 4 : 0}};
+    for (const Part &p : parts) {
+        if (!p.from) continue;
+        hipError_t e = hipMalloc(p.dst, p.alloc ? p.alloc : 16);
+        if (e == hipSuccess && p.copy) e = hipMemcpyPeerAsync(*p.dst, device, p.from, src->device, p.copy, nullptr);
+        if (e != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "replica copy %d -> %d: %s", src->device, device, hipGetErrorString(e)); }
+    }
+    {
+        const hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "replica copy %d -> %d: %s", src->device, device, hipGetErrorString(e)); }
+    }
+    const int rc = scene_finish_workspace(s);
+    if (rc) { free_scene(s); return rc; }
+    const size_t pairs_bytes = src->dev.tri_off_bytes;
+    s->dev.pairs = (const float4 *)s->d_geom;
+    s->dev.tri_pos = (const float4 *)((const char *)s->d_geom + pairs_bytes);
+    s->dev.tri_attr = (const float4 *)s->d_tri_attr;
+    s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
+    s->dev.mats_full = (const mipt::DevMaterialFull *)s->d_mats_full;
+    s->dev.texels = (const uint32_t *)s->d_texels;
+    s->info.replica_of_device = (uint32_t)src->device + 1u;
+    s->info.upload_ms = now_ms() - t0; s->info.build_ms = 0.0; s->info.layout_ms = 0.0; s->info.total_ms = s->info.upload_ms;
+    *out = s;
+    return MIPT_OK;
+}
+
+
 extern "C" {
 
 const char *mipt_last_error(void) { return g_err.c_str(); }
@@ -173,8 +285,8 @@ void mipt_material_default(MiptMaterial *m) {        // scene.rs:148-167
         m->emission_tex_id = m->normal_tex_id = UINT32_MAX;
 }
 
-// Builds the device layout ONCE on the host and uploads it to every device of `device_ids` (replicas for mipt_multi_create are
-// uploaded concurrently, one host thread per device: each upload is bound by its own PCIe link).
+// Builds the device layout ONCE on the host, uploads it to device_ids[0] and replicates it from there (device-to-device copies: xGMI
+// between the GPUs of a node) for mipt_multi_create.
 static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
     if (!desc || !outs || !device_ids || n_dev < 1) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
     for (int i = 0; i < n_dev; i++) outs[i] = nullptr;
@@ -186,6 +298,7 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     if ((desc->n_nodes & 1u) == 0u) return fail(MIPT_ERR_BVH, "node count %u is even: children are pushed in pairs after the root (bvh.rs:131-132)", desc->n_nodes);
     const uint32_t n_pairs = (desc->n_nodes - 1u) / 2u;
     if (n_pairs > mipt::kMaxPairs) return fail(MIPT_ERR_SCENE_LIMIT, "%u node pairs exceed the 2^24 device-format limit", n_pairs);
+    const double t_begin = now_ms();
 
     // ---- validate and re-base the BVH: pair[k] = {nodes[2k+1], nodes[2k+2]} ----
     uint32_t max_leaf = 0;
@@ -326,47 +439,11 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     if (bad_tri.load() != UINT32_MAX)
         return fail(MIPT_ERR_INVALID_ARG, "triangle %u has material_id %u >= n_materials %u", bad_tri.load(), desc->tris[bad_tri.load()].material_id, desc->n_materials);
     // ---- materials / textures ----
-    struct TexDesc { uint32_t offset, width, height; };
-    std::vector<TexDesc> texs(desc->n_textures);
-    uint64_t n_texels = 0;
-    for (uint32_t i = 0; i < desc->n_textures; i++) {
-        const MiptTexture &t = desc->textures[i];
-        if (!t.rgba8 || t.width == 0 || t.height == 0) return fail(MIPT_ERR_INVALID_ARG, "texture %u is empty", i);
-        if (n_texels + (uint64_t)t.width * t.height > 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "texture pool exceeds 2^32 texels");
-        texs[i] = {(uint32_t)n_texels, t.width, t.height};
-        n_texels += (uint64_t)t.width * t.height;
+    mipt::MaterialTables tables;
+    {
+        const int rc = mipt::build_material_tables(desc, &tables);
+        if (rc) return rc;
     }
-    std::vector<mipt::DevMaterial> mats(desc->n_materials);
-    for (uint32_t i = 0; i < desc->n_materials; i++) {
-        const MiptMaterial &m = desc->materials[i];
-        if ((m.base_color_tex_id != UINT32_MAX && m.base_color_tex_id >= desc->n_textures) ||
-            (m.emission_tex_id != UINT32_MAX && m.emission_tex_id >= desc->n_textures))
-            return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
-        mipt::DevMaterial d{};
-        d.base[0] = m.base_color.x; d.base[1] = m.base_color.y; d.base[2] = m.base_color.z;
-        d.emis[0] = m.emission.x; d.emis[1] = m.emission.y; d.emis[2] = m.emission.z;
-        if (m.base_color_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.base_color_tex_id]; d.base_off = t.offset; d.base_w = t.width; d.base_h = t.height; }
-        if (m.emission_tex_id != UINT32_MAX) { const TexDesc &t = texs[m.emission_tex_id]; d.emis_off = t.offset; d.emis_w = t.width; d.emis_h = t.height; }
-        mats[i] = d;
-    }
-    std::vector<mipt::DevMaterialFull> mats_full(desc->n_materials);
-    for (uint32_t i = 0; i < desc->n_materials; i++) {
-        const MiptMaterial &m = desc->materials[i];
-        mipt::DevMaterialFull f{};
-        f.base[0] = m.base_color.x; f.base[1] = m.base_color.y; f.base[2] = m.base_color.z; f.transmission = m.transmission;
-        f.emission[0] = m.emission.x; f.emission[1] = m.emission.y; f.emission[2] = m.emission.z; f.ior = m.ior;
-        f.roughness = m.roughness; f.metallic = m.metallic; f.transparency = m.transparency;
-        const uint32_t ids[6] = {m.base_color_tex_id, m.transparency_tex_id, m.roughness_tex_id, m.metallic_tex_id, m.emission_tex_id, m.normal_tex_id};
-        for (int k = 0; k < 6; k++) {
-            if (ids[k] == UINT32_MAX) continue;
-            if (ids[k] >= desc->n_textures) return fail(MIPT_ERR_INVALID_ARG, "material %u references a texture >= n_textures %u", i, desc->n_textures);
-            f.tex[k][0] = texs[ids[k]].offset; f.tex[k][1] = texs[ids[k]].width; f.tex[k][2] = texs[ids[k]].height;
-        }
-        mats_full[i] = f;
-    }
-    std::vector<uint32_t> texels((size_t)n_texels);
-    for (uint32_t i = 0; i < desc->n_textures; i++)
-        memcpy(texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
 
     if (desc->nodes[0].num_tris == 0 && desc->nodes[0].first_tri_or_child != 1u)
         return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)");
@@ -374,38 +451,30 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     const size_t pairs_bytes = pairs.size() * sizeof(float4), pos_bytes = tri_pos.size() * sizeof(float4);
     if (pairs_bytes + pos_bytes >= 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "BVH + triangle stream exceed 4 GiB");
 
-    // ---- device(s) ----
+    const double t_layout = now_ms();
+    // ---- device(s): the scene crosses PCIe once, to device_ids[0]; further replicas are device-to-device copies ----
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     for (int i = 0; i < n_dev; i++)
         if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(MIPT_ERR_HIP, "HIP device %d not available (%d visible)", device_ids[i], ndev);
-    auto upload_to = [&](int device_id, MiptScene **out) -> int {
-    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipSetDevice(device_ids[0]));
     MiptScene *s = new (std::nothrow) MiptScene();
     if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
-    s->device = device_id;
+    s->device = device_ids[0];
     s->max_leaf = max_leaf;
     s->n_tris = desc->n_tris;
     int rc;
     {
-        hipError_t e1 = hipMalloc(&s->d_geom, pairs_bytes + pos_bytes + 64);
+        s->geom_alloc = pairs_bytes + pos_bytes + 64;
+        hipError_t e1 = hipMalloc(&s->d_geom, s->geom_alloc);
         if (e1 == hipSuccess && pairs_bytes) e1 = hipMemcpy(s->d_geom, pairs.data(), pairs_bytes, hipMemcpyHostToDevice);
         if (e1 == hipSuccess) e1 = hipMemcpy((char *)s->d_geom + pairs_bytes, tri_pos.data(), pos_bytes, hipMemcpyHostToDevice);
         if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
     }
-    if ((rc = upload(&s->d_tri_attr, tri_attr)) ||
-        (rc = upload(&s->d_mats, mats, 64)) || (rc = upload(&s->d_mats_full, mats_full, 128)) || (rc = upload(&s->d_texels, texels, 16))) {
+    s->attr_bytes = tri_attr.size() * sizeof(float4);
+    if ((rc = upload(&s->d_tri_attr, tri_attr)) || (rc = mipt::upload_material_tables(s, tables)) || (rc = mipt::scene_finish_workspace(s))) {
         free_scene(s);
         return rc;
-    }
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device_id);
-    if (e != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
-    s->n_cu = prop.multiProcessorCount;
-    if ((e = hipMalloc((void **)&s->d_stats, sizeof(mipt::DevStats))) != hipSuccess ||
-        (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
-        free_scene(s);
-        return fail(MIPT_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e));
     }
     s->dev.pairs = (const float4 *)s->d_geom;
     s->dev.tri_pos = (const float4 *)((const char *)s->d_geom + pairs_bytes);
@@ -413,43 +482,25 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     s->dev.geom_bytes = (uint32_t)(pairs_bytes + pos_bytes);
     s->dev.tiny_axes = tiny_axes;
     s->dev.tri_attr = (const float4 *)s->d_tri_attr;
-    s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
-    s->dev.mats_full = (const mipt::DevMaterialFull *)s->d_mats_full;
-    s->dev.texels = (const uint32_t *)s->d_texels;
     s->dev.n_pairs = n_pair_records; s->dev.n_tris = desc->n_tris; s->dev.n_mats = desc->n_materials; s->dev.n_texs = desc->n_textures;
     // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0
     s->dev.root_a = desc->nodes[0].num_tris > 0 ? slot_of_tri[desc->nodes[0].first_tri_or_child] : 0u;
     s->dev.root_n = desc->nodes[0].num_tris;
-    *out = s;
-    return MIPT_OK;
-    };
-    if (n_dev == 1) return upload_to(device_ids[0], &outs[0]);
-    std::vector<int> rcs((size_t)n_dev, 0);
-    std::vector<std::string> errs((size_t)n_dev);
-    {
-        std::vector<std::thread> th;
-        th.reserve((size_t)n_dev);
-        auto work = [&](int i) { rcs[(size_t)i] = upload_to(device_ids[i], &outs[i]); if (rcs[(size_t)i]) errs[(size_t)i] = g_err; };
-        bool spawn_failed = false;
-        try {                                                       // a throwing std::thread constructor must not unwind past joinable threads
-            for (int i = 1; i < n_dev; i++) th.emplace_back(work, i);
-        } catch (const std::exception &) { spawn_failed = true; }
-        if (!spawn_failed) work(0);
-        for (auto &t : th) t.join();
-        if (spawn_failed) {
+    const double t_up = now_ms();
+    s->info.n_tris = desc->n_tris; s->info.n_nodes = desc->n_nodes; s->info.n_pair_records = n_pair_records; s->info.max_leaf = max_leaf;
+    s->info.geometry_bytes = (uint64_t)pairs_bytes + pos_bytes + s->attr_bytes;
+    s->info.layout_ms = t_layout - t_begin; s->info.upload_ms = t_up - t_layout; s->info.total_ms = t_up - t_begin;
+    outs[0] = s;
+    for (int i = 1; i < n_dev; i++) {
+        if ((rc = mipt::scene_clone_to(s, device_ids[i], &outs[i]))) {
+            const std::string msg = g_err;
             for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
-            return fail(MIPT_ERR_HIP, "mipt_multi_create: could not start a host thread per device");
+            return fail(rc, "replica on device %d: %s", device_ids[i], msg.c_str());
         }
     }
-    for (int i = 0; i < n_dev; i++)
-        if (rcs[(size_t)i]) {
-            const int rc = rcs[(size_t)i];
-            const std::string msg = "device " + std::to_string(device_ids[i]) + ": " + errs[(size_t)i];
-            for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
-            return fail(rc, "%s", msg.c_str());
-        }
     return MIPT_OK;
 }
+
 static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
     if (!out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create: null argument");
     *out = nullptr;
@@ -463,13 +514,46 @@ static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene
     catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, "internal error: %s", e.what()); }
 int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out) { MIPT_NO_THROW(scene_create_impl(desc, device_id, out)) }
 } // extern "C"
-// internal (mipt_multi.cpp): one host-side layout build, n uploads
-int mipt::scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
-    MIPT_NO_THROW(scene_create_many(desc, device_ids, n_dev, outs))
+// internal (mipt_multi.cpp): one scene on device_ids[0], device-to-device replicas on the others
+static int scene_create_many_from_triangles(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs) {
+    if (!desc || !outs || !device_ids || n_dev < 1) return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_create_from_triangles: null argument");
+    for (int i = 0; i < n_dev; i++) outs[i] = nullptr;
+    int rc = mipt::scene_create_from_triangles(desc, device_ids[0], &outs[0]);
+    for (int i = 1; i < n_dev && rc == MIPT_OK; i++) {
+        rc = mipt::scene_clone_to(outs[0], device_ids[i], &outs[i]);
+        if (rc) { const std::string msg = g_err; fail(rc, "replica on device %d: %s", device_ids[i], msg.c_str()); }
+    }
+    if (rc) {
+        const std::string msg = g_err;
+        for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
+        g_err = msg;
+    }
+    return rc;
+}
+int mipt::scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs, bool from_triangles) {
+    MIPT_NO_THROW(from_triangles ? scene_create_many_from_triangles(desc, device_ids, n_dev, outs) : scene_create_many(desc, device_ids, n_dev, outs))
 }
 extern "C" {
 
 void mipt_scene_destroy(MiptScene *scene) { free_scene(scene); }
+
+int mipt_scene_info(const MiptScene *scene, MiptSceneInfo *out) {
+    if (!scene || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_info: null argument");
+    *out = scene->info;
+    return MIPT_OK;
+}
+
+int mipt_scene_get_bvh(MiptScene *scene, MiptNode *nodes_out, uint32_t nodes_cap, uint32_t *n_nodes_out, uint32_t *tri_order_out) {
+    if (!scene || !nodes_out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_get_bvh: null argument");
+    if (!scene->d_nodes || !scene->d_tri_order)
+        return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_get_bvh: this scene was created from host-built nodes (the caller already has them)");
+    if (nodes_cap < scene->n_nodes) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_get_bvh: nodes_cap %u < %u nodes", nodes_cap, scene->n_nodes);
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipMemcpy(nodes_out, scene->d_nodes, (size_t)scene->n_nodes * sizeof(MiptNode), hipMemcpyDeviceToHost));
+    if (tri_order_out) HIP_TRY(hipMemcpy(tri_order_out, scene->d_tri_order, scene->n_tris * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (n_nodes_out) *n_nodes_out = scene->n_nodes;
+    return MIPT_OK;
+}
 
 uint64_t mipt_packed_pixels(uint32_t width, uint32_t height, uint32_t tile_world) {
     if (tile_world == 0) tile_world = 1;

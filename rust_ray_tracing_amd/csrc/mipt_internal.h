@@ -16,9 +16,14 @@ uint32_t pair_order_top();                               // number of breadth-fi
 // Slot of every triangle's 64-B record in the intersection stream.
 int tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t *slot_out, uint32_t *n_slots_out);
 
+// ---- scene_device.hip ----
+// mipt_scene_create_from_triangles without the exception fence.
+int scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out);
+
 // ---- mipt_api.cpp, used by mipt_multi.cpp ----
-// One host-side layout build, n uploads (replicas for mipt_multi_create).
-int scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs);
+// One scene on device_ids[0] -- from host-built nodes (one host-side layout build, one upload) or, with from_triangles, built on that
+// device -- and device-to-device replicas on the others.
+int scene_create_replicas(const MiptSceneDesc *desc, const int *device_ids, int n_dev, MiptScene **outs, bool from_triangles);
 // mipt_render_device with `pack_single`: honour MIPT_FLAG_PACKED also at tile_world == 1.
 int render_device_impl(MiptScene *scene, const MiptCamera *camera, const MiptOptions *opt, float *d_hdr_rgb, uint8_t *d_rgba8,
                        void *hip_stream, MiptStats *stats, bool pack_single);

@@ -107,7 +107,7 @@ void destroy(MiptMulti *m) {
     delete m;
 }
 
-int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out) {
+int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out, bool from_triangles) {
     if (!desc || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_create: null argument");
     *out = nullptr;
     const int visible = mipt_device_count();
@@ -129,9 +129,10 @@ int create_impl(const MiptSceneDesc *desc, const int *device_ids, int n_devices,
     m->d_part.assign(n_devices, nullptr);
     m->part_floats.assign(n_devices, 0);
     m->last.assign(n_devices, MiptStats{});
-    // scene replicas: the device layout is built once on the host, the uploads run concurrently (one host thread per device)
+    // scene replicas: the scene reaches device 0 once (host layout + upload, or built there from the triangles); the others are
+    // device-to-device copies
     {
-        const int rc = mipt::scene_create_replicas(desc, m->devices.data(), n_devices, m->scenes.data());
+        const int rc = mipt::scene_create_replicas(desc, m->devices.data(), n_devices, m->scenes.data(), from_triangles);
         if (rc) { const std::string e = mipt_last_error(); destroy(m); return fail(rc, e); }
     }
     for (int i = 0; i < n_devices; i++) {
@@ -329,9 +330,16 @@ int render_impl(MiptMulti *m, const MiptCamera *camera, const MiptOptions *opt, 
 extern "C" {
 
 int mipt_multi_create(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out) {
-    try { return create_impl(desc, device_ids, n_devices, out); }
+    try { return create_impl(desc, device_ids, n_devices, out, false); }
     catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, std::string("internal error: ") + e.what()); }
 }
+
+int mipt_multi_create_from_triangles(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out) {
+    try { return create_impl(desc, device_ids, n_devices, out, true); }
+    catch (const std::exception &e) { return fail(MIPT_ERR_INVALID_ARG, std::string("internal error: ") + e.what()); }
+}
+
+MiptScene *mipt_multi_scene(MiptMulti *m, int index) { return (m && index >= 0 && index < m->n) ? m->scenes[(size_t)index] : nullptr; }
 
 void mipt_multi_destroy(MiptMulti *m) { destroy(m); }
 

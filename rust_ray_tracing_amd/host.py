@@ -202,6 +202,38 @@ class Scene:  # scene.rs:12-19
         self._handle, self._handle_device = h, device_id
         return h
 
+    def upload_from_triangles(self, device_id: int = 0, fetch_bvh: bool = False) -> C.c_void_p:
+        """BVH::build + upload in ONE call, everything after the triangle copy on the GPU (mipt_scene_create_from_triangles): the
+        scene's triangles go up in their current order, the tree is built and laid out in HBM.  With ``fetch_bvh`` the Scene is
+        left as BVH::build leaves the reference's (bvh.rs:13-54): ``bvh_nodes`` filled and ``tris`` reordered."""
+        self.release()
+        h = C.c_void_p()
+        d = self.desc()
+        lib = L.load()
+        L.check(lib.mipt_scene_create_from_triangles(C.byref(d), device_id, C.byref(h)), "mipt_scene_create_from_triangles")
+        self._handle, self._handle_device = h, device_id
+        if fetch_bvh:
+            self._fetch_bvh(h)
+        return h
+
+    def _fetch_bvh(self, handle) -> None:
+        n = len(self.tris)
+        nodes = np.zeros(max(2 * n, 1), dtype=L.NODE)
+        order = np.zeros(n, dtype=np.uint32)
+        count = C.c_uint32(0)
+        L.check(L.load().mipt_scene_get_bvh(handle, L.ptr(nodes), len(nodes), C.byref(count), L.ptr(order)), "mipt_scene_get_bvh")
+        self.bvh_nodes = nodes[: count.value].copy()
+        self.tris = self.tris[order]
+
+    def info(self, handle=None) -> dict:
+        """MiptSceneInfo of the resident scene (sizes + what the setup took)."""
+        h = handle if handle is not None else self._handle
+        if h is None:
+            raise RuntimeError("scene is not resident on a device")
+        inf = L.MiptSceneInfo()
+        L.check(L.load().mipt_scene_info(h, C.byref(inf)), "mipt_scene_info")
+        return inf.as_dict()
+
     def release(self) -> None:
         if self._handle is not None:
             L.load().mipt_scene_destroy(self._handle)
@@ -210,9 +242,11 @@ class Scene:  # scene.rs:12-19
             L.load().mipt_multi_destroy(self._multi)
             self._multi = None
 
-    def upload_multi(self, device_ids=None) -> C.c_void_p:
-        """One replica + RCCL communicator per device (mipt_multi_create); device_ids None = every visible device."""
-        key = None if device_ids is None else tuple(device_ids)
+    def upload_multi(self, device_ids=None, from_triangles: bool = False, fetch_bvh: bool = False) -> C.c_void_p:
+        """One replica + RCCL communicator per device (mipt_multi_create); device_ids None = every visible device.  The scene crosses
+        PCIe once (to the first device), the other replicas are device-to-device copies.  ``from_triangles``: the BVH is built on
+        that first device (mipt_multi_create_from_triangles); ``fetch_bvh`` then leaves nodes + reordered triangles in this Scene."""
+        key = (None if device_ids is None else tuple(device_ids), from_triangles)
         if getattr(self, "_multi", None) is not None and self._multi_key == key:
             return self._multi
         if getattr(self, "_multi", None) is not None:
@@ -221,7 +255,13 @@ class Scene:  # scene.rs:12-19
         h = C.c_void_p()
         d = self.desc()
         ids = None if device_ids is None else (C.c_int * len(device_ids))(*device_ids)
-        L.check(L.load().mipt_multi_create(C.byref(d), ids, 0 if device_ids is None else len(device_ids), C.byref(h)), "mipt_multi_create")
+        lib = L.load()
+        if from_triangles:
+            L.check(lib.mipt_multi_create_from_triangles(C.byref(d), ids, 0 if device_ids is None else len(device_ids), C.byref(h)), "mipt_multi_create_from_triangles")
+            if fetch_bvh:
+                self._fetch_bvh(lib.mipt_multi_scene(h, 0))
+        else:
+            L.check(lib.mipt_multi_create(C.byref(d), ids, 0 if device_ids is None else len(device_ids), C.byref(h)), "mipt_multi_create")
         self._multi, self._multi_key = h, key
         return h
 

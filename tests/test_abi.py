@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported(rrt):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/mipt.h but not exported by libmipt.so"
     assert sorted(L.EXPORTS) == syms, "binding list and header disagree"
-    assert lib.mipt_abi_version() == 3
+    assert lib.mipt_abi_version() == 4
 
 
 def _dynamic_symbols(path):

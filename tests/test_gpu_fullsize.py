@@ -21,11 +21,51 @@ def atrium10m(rrt):
     tris, mats, texs, cam = synth.atrium_scene(n_target=10_000_000, tex_size=1024)
     sc = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
     del tris
-    sc.build_bvh_device(0)                       # identical tree to the host builder (tests/test_gpu_more.py), 10x faster
+    # triangles up once, BVH::build + device layout in HBM (identical tree and layout to the host path: tests/test_gpu_scene_device.py
+    # and test_device_resident_setup_at_full_size below); the Scene is left as BVH::build leaves it (nodes + reordered triangles)
+    sc.upload_from_triangles(0, fetch_bvh=True)
     sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
-    sc.upload(0)
     yield sc
     sc.release()
+
+
+def test_device_resident_setup_at_full_size(rrt, atrium10m):
+    """10 M triangles: the layout the GPU kernels built is byte-identical (order-dependent 64-bit fingerprints of both buffers) to the
+    host code's layout of the same tree, config M's frame is the same frame, and the whole setup call is a fraction of a second."""
+    import zlib
+    from rust_ray_tracing_amd import _lib as L
+    sc = atrium10m
+    info = sc.info()
+    print(f"device-resident setup: total {info['total_ms']:.0f} ms (upload {info['upload_ms']:.0f}, build {info['build_ms']:.1f}, layout {info['layout_ms']:.0f}); "
+          f"{info['n_nodes']} nodes, {info['n_pair_records']} pair records, {info['geometry_bytes'] / 1e9:.2f} GB")
+    assert info["built_on_device"] == 1 and info["n_tris"] == len(sc.tris) > 9_900_000
+    assert info["total_ms"] < 600.0                      # bench.py reports the figure; this only guards against a regression to seconds
+    diag = rrt.load_diag()
+    h_dev = (C.c_uint64 * 2)()
+    assert diag.mipt_diag_scene_hash(sc.upload(0), C.byref(h_dev)) == 0
+    w, h, spp, depth = 1920, 1080, 8, 64
+    opt = rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_CULLED, flags=L.FLAG_COUNT)
+    f_dev, st_dev = _device_render(rrt, sc, opt, w * h * 3)
+    crc_dev = zlib.crc32(f_dev.cpu().numpy().tobytes()) & 0xFFFFFFFF
+    # the host path on the same tree: mipt_scene_create lays the records out on the CPU
+    host = rrt.Scene.from_arrays(sc.tris, list(sc.materials.values()), sc.textures, build_bvh=False)
+    host.bvh_nodes = sc.bvh_nodes
+    host.camera = sc.camera
+    hh = host.upload(0)
+    try:
+        h_host = (C.c_uint64 * 2)()
+        assert diag.mipt_diag_scene_hash(hh, C.byref(h_host)) == 0
+        assert list(h_dev) == list(h_host)
+        hi = host.info()
+        for k in ("n_nodes", "n_pair_records", "max_leaf", "geometry_bytes"):
+            assert hi[k] == info[k], k
+        f_host, st_host = _device_render(rrt, host, opt, w * h * 3)
+        assert zlib.crc32(f_host.cpu().numpy().tobytes()) & 0xFFFFFFFF == crc_dev
+        for k in ("rays", "inner_steps", "tri_tests", "hits"):
+            assert st_dev[k] == st_host[k], k
+        print(f"frame crc {crc_dev:08x}; host path: layout {hi['layout_ms']:.0f} ms + upload {hi['upload_ms']:.0f} ms")
+    finally:
+        host.release()
 
 
 def _device_render(rrt, sc, opt, n_floats):

@@ -1,0 +1,193 @@
+"""-m gpu: device-resident scene setup -- mipt_scene_create_from_triangles ("make scene load interactive").
+
+The triangle array crosses PCIe once; BVH::build (reference src/bvh.rs:13-161) and the whole device layout are produced by GPU
+kernels (csrc/bvh_build_device.hip, csrc/scene_device.hip).  Checked here:
+  * the tree and the triangle order it reports are the host builder's (= the reference's), node for node;
+  * the device layout -- pair records | intersection stream, attribute stream -- is BYTE-identical to what mipt_scene_create's host
+    code lays out from the same tree (read back through libmipt_diag.so);
+  * frames and all counters equal the host-path scene's and the oracle's;
+  * replicas made by device-to-device copy render the same frame; errors are status codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _soup(n, seed, degenerate=False):
+    from rust_ray_tracing_amd import TRIANGLE
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, dtype=TRIANGLE)
+    c = rng.uniform(-4, 4, (n, 1, 3)).astype(np.float32)
+    t["vertices"]["position"] = c + rng.normal(0, 0.3, (n, 3, 3)).astype(np.float32)
+    t["vertices"]["normal"] = rng.normal(0, 1, (n, 3, 3)).astype(np.float32)
+    t["vertices"]["tex_coord_x"] = rng.uniform(0, 4, (n, 3)).astype(np.float32)
+    t["vertices"]["tex_coord_y"] = rng.uniform(0, 4, (n, 3)).astype(np.float32)
+    if degenerate:                                             # coincident triangles, zero-area triangles, axis-aligned slabs, exact zeros
+        t[n // 4: n // 2] = t[n // 4]
+        t["vertices"]["position"][n // 2: n // 2 + n // 8, 1] = t["vertices"]["position"][n // 2: n // 2 + n // 8, 0]
+        t["vertices"]["position"][-(n // 8):, :, 2] = 0.0
+    return t
+
+
+def _cases():
+    from rust_ray_tracing_amd import synth
+    out = []
+    for kind, kw in (("cornell", {}), ("helmet", dict(n_target=3000, tex_size=16)), ("atrium", dict(n_target=20000, tex_size=16)),
+                     ("dragon", dict(n_target=20000))):
+        tris, mats, texs, cam = synth.make_scene(kind, **kw)
+        out.append((kind, tris, mats, texs, cam))
+    return out
+
+
+def _layout(rrt, handle):
+    diag = rrt.load_diag()
+    sizes = (C.c_uint64 * 2)()
+    assert diag.mipt_diag_scene_sizes(handle, C.byref(sizes)) == 0
+    geom = np.zeros(sizes[0], dtype=np.uint8)
+    attr = np.zeros(sizes[1], dtype=np.uint8)
+    assert diag.mipt_diag_scene_read(handle, 0, geom.ctypes.data, sizes[0]) == 0
+    assert diag.mipt_diag_scene_read(handle, 1, attr.ctypes.data, sizes[1]) == 0
+    h = (C.c_uint64 * 2)()
+    assert diag.mipt_diag_scene_hash(handle, C.byref(h)) == 0
+    return geom, attr, (int(h[0]), int(h[1]))
+
+
+def _same_nodes(a, b):
+    """node arrays equal; a bound may differ in the sign of a zero (documented for the device builder)"""
+    return (len(a) == len(b) and np.array_equal(a["first_tri_or_child"], b["first_tri_or_child"]) and np.array_equal(a["num_tris"], b["num_tris"])
+            and np.array_equal(a["bounds_min"], b["bounds_min"]) and np.array_equal(a["bounds_max"], b["bounds_max"]))
+
+
+def _check_scene(rrt, orc, tris, mats, texs, cam, w=96, h=54, spp=2, depth=8, oracle=True):
+    from rust_ray_tracing_amd import _lib as L
+    dev = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
+    hd = dev.upload_from_triangles(0, fetch_bvh=True)
+    info = dev.info()
+    assert info["built_on_device"] == 1 and info["n_tris"] == len(tris) and info["n_nodes"] == len(dev.bvh_nodes) and info["build_ms"] > 0.0
+    # 1. the tree is the host builder's
+    host = rrt.Scene.from_arrays(tris, mats, texs)
+    assert _same_nodes(dev.bvh_nodes, host.bvh_nodes)
+    assert dev.tris.tobytes() == host.tris.tobytes()
+    # 2. the layout is what the host code builds from that tree
+    ref = rrt.Scene.from_arrays(dev.tris, mats, texs, build_bvh=False)
+    ref.bvh_nodes = dev.bvh_nodes.copy()
+    hr = ref.upload(0)
+    g1, a1, h1 = _layout(rrt, hd)
+    g2, a2, h2 = _layout(rrt, hr)
+    assert g1.size == g2.size and a1.size == a2.size
+    assert np.array_equal(a1, a2), "attribute stream differs"
+    if not np.array_equal(g1, g2):
+        bad = np.flatnonzero(g1 != g2)
+        raise AssertionError(f"geometry differs in {bad.size} bytes, first at {bad[0]} (record {bad[0] // 64}) of {g1.size}")
+    assert h1 == h2
+    ri, hi = ref.info(), dev.info()
+    for k in ("n_tris", "n_nodes", "n_pair_records", "max_leaf", "geometry_bytes"):
+        assert ri[k] == hi[k], k
+    # 3. frames and counters
+    for s_ in (dev, ref):
+        s_.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h), output_image_path="/dev/null"))
+    f1, p1, s1 = r.render_buffers(dev, flags=L.FLAG_COUNT)
+    f2, p2, s2 = r.render_buffers(ref, flags=L.FLAG_COUNT)
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32)) and np.array_equal(p1, p2)
+    for k in ("rays", "inner_steps", "tri_tests", "hits", "texel_fetches", "pixels", "max_stack"):
+        assert s1[k] == s2[k], k
+    if oracle:
+        of, op_, os_ = orc.render(dev.tris, dev.bvh_nodes, dev.materials_array(), dev.textures, dev.camera.uniform, w, h, spp, depth)
+        assert np.array_equal(f1.view(np.uint32), of.view(np.uint32)) and np.array_equal(p1, op_)
+        assert s1["rays"] == os_["rays"] and s1["tri_tests"] == os_["tri_tests"]
+    return dev
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_scene_families(rrt, orc, idx):
+    kind, tris, mats, texs, cam = _cases()[idx]
+    _check_scene(rrt, orc, tris, mats, texs, cam)
+
+
+@pytest.mark.parametrize("n,seed,degenerate", [(1, 1, False), (2, 2, False), (3, 3, False), (17, 4, False), (300, 5, True), (5000, 6, False),
+                                               (40000, 7, True), (70001, 8, False)])
+def test_random_soups(rrt, orc, n, seed, degenerate):
+    """sizes around every node class of the builder (one thread / wave / workgroup / many workgroups) and around the scan tiles"""
+    tris = _soup(n, seed, degenerate)
+    _check_scene(rrt, orc, tris, [rrt.material_default()], [], ((12.0, 0.5, 0.3), 0.0, 0.0), w=64, h=36, spp=1, depth=4)
+
+
+def test_errors_are_status_codes(rrt):
+    from rust_ray_tracing_amd import _lib as L
+    lib = rrt.load()
+    h = C.c_void_p()
+    assert lib.mipt_scene_create_from_triangles(None, 0, C.byref(h)) == L.ERR_INVALID_ARG
+    d = L.MiptSceneDesc()
+    assert lib.mipt_scene_create_from_triangles(C.byref(d), 0, C.byref(h)) == L.ERR_INVALID_ARG and b"no triangles" in lib.mipt_last_error()
+    tris = _soup(100, 9)
+    tris["material_id"][37] = 5
+    sc = rrt.Scene.from_arrays(tris, [rrt.material_default()], [], build_bvh=False)
+    tris = sc.tris                                                        # (from_arrays copies)
+    d = sc.desc()
+    assert lib.mipt_scene_create_from_triangles(C.byref(d), 0, C.byref(h)) == L.ERR_INVALID_ARG and b"material_id" in lib.mipt_last_error()
+    assert h.value is None
+    tris["material_id"][37] = 0
+    assert lib.mipt_scene_create_from_triangles(C.byref(d), 99, C.byref(h)) == L.ERR_HIP
+    tris["vertices"]["position"][5, 1, 0] = 3e12                         # beyond the exact-division guard's 2^40: refused like mipt_scene_create
+    assert lib.mipt_scene_create_from_triangles(C.byref(d), 0, C.byref(h)) == L.ERR_SCENE_LIMIT
+    tris["vertices"]["position"][5, 1, 0] = np.nan
+    rc = lib.mipt_scene_create_from_triangles(C.byref(d), 0, C.byref(h))
+    assert rc in (L.ERR_SCENE_LIMIT, L.OK)                                # a NaN vertex is ignored by f32 min/max (bvh.rs:185-194): bounds stay finite
+    if rc == L.OK:
+        lib.mipt_scene_destroy(h)
+    # a scene made from host-built nodes has no tree to give back
+    host = rrt.Scene.from_arrays(_soup(50, 10), [rrt.material_default()])
+    hh = host.upload(0)
+    nodes = np.zeros(100, dtype=L.NODE)
+    assert lib.mipt_scene_get_bvh(hh, L.ptr(nodes), 100, None, None) == L.ERR_INVALID_ARG
+    dev = rrt.Scene.from_arrays(_soup(50, 10), [rrt.material_default()], build_bvh=False)
+    hd = dev.upload_from_triangles(0)
+    assert lib.mipt_scene_get_bvh(hd, L.ptr(nodes), 3, None, None) == L.ERR_INVALID_ARG and b"nodes_cap" in lib.mipt_last_error()
+    cnt = C.c_uint32()
+    assert lib.mipt_scene_get_bvh(hd, L.ptr(nodes), 100, C.byref(cnt), None) == 0 and cnt.value == dev.info()["n_nodes"]
+
+
+def test_replicas_by_device_to_device_copy(rrt, orc):
+    """mipt_multi_create_from_triangles over three logical ranks (libmipt_multitest.so): device 0 builds, ranks 1 and 2 are
+    device-to-device replicas; the tiles frame equals the single-scene frame and the oracle's."""
+    from rust_ray_tracing_amd import _lib as L
+    from rust_ray_tracing_amd import synth
+    mt = L.load_multitest()
+    tris, mats, texs, cam = synth.make_scene("atrium", n_target=20000, tex_size=16)
+    sc = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
+    sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    d = sc.desc()
+    m = C.c_void_p()
+    assert mt.mipt_multi_create_from_triangles(C.byref(d), (C.c_int * 3)(0, 0, 0), 3, C.byref(m)) == 0, mt.mipt_last_error()
+    try:
+        infos = []
+        for i in range(3):
+            inf = L.MiptSceneInfo()
+            assert mt.mipt_scene_info(mt.mipt_multi_scene(m, i), C.byref(inf)) == 0
+            infos.append(inf.as_dict())
+        assert infos[0]["built_on_device"] == 1 and infos[0]["replica_of_device"] == 0
+        assert all(x["replica_of_device"] == 1 and x["n_pair_records"] == infos[0]["n_pair_records"] for x in infos[1:])
+        assert mt.mipt_multi_scene(m, 3) is None
+        n = len(tris)
+        nodes = np.zeros(2 * n, dtype=L.NODE)
+        order = np.zeros(n, dtype=np.uint32)
+        cnt = C.c_uint32()
+        assert mt.mipt_scene_get_bvh(mt.mipt_multi_scene(m, 2), L.ptr(nodes), len(nodes), C.byref(cnt), L.ptr(order)) == 0     # the replica carries the tree too
+        w, h, spp, depth = 128, 72, 2, 8
+        opt = rrt.make_options(w, h, spp, depth, flags=L.FLAG_COUNT)
+        hdr = np.zeros((h, w, 3), dtype=np.float32)
+        st = L.MiptMultiStats()
+        assert mt.mipt_render_multi(m, L.ptr(sc.camera.uniform), C.byref(opt), L.MULTI_TILES, L.ptr(hdr), None, C.byref(st)) == 0, mt.mipt_last_error()
+        ref, _, ost = orc.render(tris[order], nodes[: cnt.value], sc.materials_array(), sc.textures, sc.camera.uniform, w, h, spp, depth)
+        assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)) and st.total.rays == ost["rays"]
+    finally:
+        mt.mipt_multi_destroy(m)
+    # the product: host-built nodes, replicas through mipt_multi_create -> same upload-once path with one device
+    sc2 = rrt.Scene.from_arrays(tris, mats, texs)
+    sc2.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    r = rrt.Renderer.new(rrt.RendererOptions(samples=spp, max_ray_depth=depth, output_image_dimensions=(w, h), output_image_path="/dev/null"))
+    f2, _, _ = r.render_buffers_multi(sc2, mode=L.MULTI_TILES, device_ids=[0])
+    assert np.array_equal(f2.view(np.uint32), hdr.view(np.uint32))
