@@ -25,7 +25,6 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
-import hashlib
 import json
 import os
 import sys
@@ -60,18 +59,7 @@ def device_bytes(st: dict, n_pixels: int) -> int:
     return (64 * st["inner_steps"] + 64 * st["tri_tests"] + 128 * st["hits"] + 4 * st["texel_fetches"] + 12 * n_pixels)
 
 
-# everything that decides what the trace kernel executes and what it reads: the kernel, its math, the device layout built by
-# mipt_api.cpp and the order of the pair records (bvh_build.cpp: mipt_internal_pair_order)
-KERNEL_SOURCES = ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp", "bvh_build.cpp")
-
-
-def kernel_source_sha() -> str:
-    """Identifies the trace kernel's source: a committed PMC summary is only quoted if it was measured on this source."""
-    h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "rust_ray_tracing_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+from rust_ray_tracing_amd.provenance import kernel_source_sha  # noqa: E402
 
 
 def pmc_traffic(n_tris_requested, w, h, spp, depth, traversal, mode):
@@ -82,7 +70,7 @@ def pmc_traffic(n_tris_requested, w, h, spp, depth, traversal, mode):
     if (n_tris_requested, w, h, spp, depth, traversal, mode) != (10_000_000, 1920, 1080, 8, 64, "culled", "tiles"):
         return None, "not the profiled configuration"
     why = "no PMC summary under profiles/"
-    for name in ("r3_pmc_summary.csv", "r2_pmc_summary.csv"):
+    for name in ("r4_pmc_summary.csv", "r3_pmc_summary.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -236,19 +224,30 @@ def main():
     tris, mats, texs, cam = synth.atrium_scene(n_target=args.tris, tex_size=args.tex_size)
     scene = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
     del tris
-    t1 = time.time()
-    bvh_ms = scene.build_bvh_device(local_rank)        # identical tree to BVH::build (bvh.rs:13-161), tests/test_gpu_more.py
-    t2 = time.time()
     scene.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+    torch.cuda.synchronize(dev)
+    t1 = time.time()
+    # Scene setup = ONE call: the triangle array crosses PCIe once, BVH::build (bvh.rs:13-161) and the device layout are produced in
+    # HBM (mipt_scene_create_from_triangles; identical tree and byte-identical layout to the host path, tests/test_gpu_scene_device.py).
     if single:
-        multi = scene.upload_multi(list(range(world)))   # one replica + stream + RCCL communicator per device, uploads concurrent
+        multi = scene.upload_multi(list(range(world)), from_triangles=True)   # device 0 builds; replicas are device-to-device copies
         handle = None
+        first = lib.mipt_multi_scene(multi, 0)
     else:
         multi = None
-        handle = scene.upload(local_rank)
+        handle = first = scene.upload_from_triangles(local_rank)
+    t2 = time.time()
+    setup_info = scene.info(first)
+    replica_ms = []
+    if single:
+        for i in range(1, world):
+            replica_ms.append(round(scene.info(lib.mipt_multi_scene(multi, i))["total_ms"], 1))
+    # for the oracle legs below (outside every timed region): the tree and the triangle order BVH::build leaves in the host's Scene
+    scene._fetch_bvh(first)
     t3 = time.time()
-    log(rank, f"scene: {len(scene.tris)} tris, {len(scene.bvh_nodes)} nodes; gen {t1 - t0:.1f}s, device bvh {bvh_ms:.0f} ms ({t2 - t1:.1f}s with transfers), "
-              f"upload {t3 - t2:.1f}s" + (f" ({world} replicas, one process)" if single else ""))
+    log(rank, f"scene: {len(scene.tris)} tris, {len(scene.bvh_nodes)} nodes; gen {t1 - t0:.1f}s, setup call {t2 - t1:.3f}s "
+              f"(upload {setup_info['upload_ms']:.0f} ms, device bvh {setup_info['build_ms']:.1f} ms, device layout {setup_info['layout_ms']:.1f} ms), "
+              f"tree read-back for the oracle {t3 - t2:.2f}s" + (f" ({world} replicas, one process: {replica_ms} ms)" if single else ""))
 
     w, h, spp, depth = args.width, args.height, args.spp, args.depth
     trav = L.TRAVERSAL_CULLED if args.traversal == "culled" else L.TRAVERSAL_REFERENCE
@@ -256,6 +255,7 @@ def main():
     cam_ptr = L.ptr(scene.camera.uniform)
     stream = torch.cuda.current_stream(dev)
     d_frame = torch.empty(n_pix * 3, dtype=torch.float32, device=dev)
+    d_rgba = torch.empty(n_pix * 4, dtype=torch.uint8, device=dev)       # cpu::render_scene's Vec<u8> (cpu.rs:60-67): part of every timed frame
     if not single:
         n_slot = int(lib.mipt_packed_pixels(w, h, world)) if world > 1 else n_pix
         d_local = torch.empty(max(n_slot, n_pix) * 3, dtype=torch.float32, device=dev)
@@ -269,7 +269,12 @@ def main():
         else:
             torch.cuda.synchronize(dev)
 
-    def render(mode, extra_flags=0, traversal=trav, out=None):
+    def tonemap(divisor=1.0):
+        """sRGB + quantise epilogue of cpu.rs:60-64 on the assembled frame (N > 1 / samples mode: after the collective)."""
+        L.check(lib.mipt_tonemap_device(C.c_void_p(d_frame.data_ptr()), n_pix, C.c_float(divisor), C.c_void_p(d_rgba.data_ptr()),
+                                        C.c_void_p(stream.cuda_stream)), "mipt_tonemap_device")
+
+    def render(mode, extra_flags=0, traversal=trav, out=None, rgba=None):
         """One launch of this rank's share in `mode`; returns MiptStats as a dict."""
         if mode == "tiles":
             opt = rrt.make_options(w, h, spp, depth, L.SEED_PIXEL_STREAM, traversal, (L.FLAG_PACKED if world > 1 else 0) | extra_flags,
@@ -279,7 +284,7 @@ def main():
                                    sample_begin=s_begin, cull_margin=L.CULL_MARGIN_SAFE)
         st = L.MiptStats()
         buf = d_local if out is None else out
-        L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt), C.c_void_p(buf.data_ptr()), None,
+        L.check(lib.mipt_render_device(handle, cam_ptr, C.byref(opt), C.c_void_p(buf.data_ptr()), None if rgba is None else C.c_void_p(rgba.data_ptr()),
                                        C.c_void_p(stream.cuda_stream), C.byref(st)), "mipt_render_device")
         return st.as_dict()
 
@@ -289,12 +294,15 @@ def main():
                                cull_margin=L.CULL_MARGIN_SAFE)
         st = L.MiptMultiStats()
         L.check(lib.mipt_render_multi_device(multi, cam_ptr, C.byref(opt), L.MULTI_TILES if mode == "tiles" else L.MULTI_SAMPLES,
-                                             C.c_void_p(d_frame.data_ptr()), None, C.byref(st)), "mipt_render_multi_device")
+                                             C.c_void_p(d_frame.data_ptr()), C.c_void_p(d_rgba.data_ptr()), C.byref(st)), "mipt_render_multi_device")
         return st.as_dict()
 
     def step(mode):
+        """One whole frame = cpu::render_scene (cpu.rs:13-68): trace, (collective,) mean, sRGB, RGBA8."""
         if single:
             return render_node(mode)
+        if mode == "tiles" and world == 1:
+            return render(mode, out=d_frame, rgba=d_rgba)            # trace kernel + tonemap kernel on the same stream, one call
         if mode == "samples" and s_count == 0:                      # more ranks than samples: this rank contributes zeros
             d_local.zero_()
             st = {"kernel_ms": 0.0}
@@ -311,8 +319,7 @@ def main():
                     dist.all_gather_into_tensor(d_all, part)
                 L.check(lib.mipt_unpack_tiles(C.c_void_p(d_all.data_ptr()), w, h, world, C.c_void_p(d_frame.data_ptr()),
                                               C.c_void_p(stream.cuda_stream)), "mipt_unpack_tiles")
-            else:
-                d_frame.copy_(d_local[: n_pix * 3])
+            tonemap()
         else:
             part = d_local[: n_pix * 3]
             if world > 1:
@@ -323,6 +330,7 @@ def main():
                 else:
                     dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)   # ONE ncclReduce(sum, f32) of the HDR sums
             torch.div(part, float(spp), out=d_frame)                 # cpu.rs:60, once, on the reduced sum (rank 0's is the frame)
+            tonemap()
         return st
 
     def count(mode):
@@ -407,12 +415,14 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"atrium stand-in for Intel Sponza + curtains: {len(scene.tris)} tris, {len(scene.bvh_nodes)} BVH nodes, "
-                               f"{w}x{h}, {spp} spp, max_ray_depth {depth}, traversal {args.traversal}"
+                               f"{w}x{h}, {spp} spp, max_ray_depth {depth}, whole frame incl. the sRGB + RGBA8 epilogue (cpu.rs:60-67), traversal {args.traversal}"
                                + (f" (margin {L.CULL_MARGIN_SAFE})" if args.traversal == "culled" else "") + f", {seeds}",
                    "mode": mode, "sharding": shard, "launch": "single-process" if single else ("torch.distributed.run" if world > 1 else "single-gpu"),
                    "rays_per_frame": tot["rays"], "paths_per_frame": n_pix * spp, "frame_crc32": f"{frame_crc:08x}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_is": "algorithmic (the contract's definition: SURVEY 8(d) bytes / kernel time / 8 TB/s) -- NOT bytes moved; the physical "
+                                "figures are memside_frac_measured (memory side, PMC) and step_roof.frac (the kernel's own roof)",
                      "basis": "ALGORITHMIC bytes in the reference's layouts (Node 32 B, Triangle 112 B, Material 80 B; SURVEY 8(d)) / kernel time. "
                               "A cache-side figure of merit that may exceed 1: most of these bytes are L1/L2 hits and the device layout is leaner -- "
                               "see device_GBs (requested by the kernel's loads) and traffic / memside_frac_measured (memory side, measured)",
@@ -441,7 +451,9 @@ def main():
     }
     if single:
         result["single_process"] = {
-            "entry": "mipt_render_multi_device (frame stays on device 0; no D2H in the timed region)",
+            "entry": "mipt_render_multi_device (frame + RGBA8 stay on device 0; no D2H in the timed region)",
+            "n_gt_1_evidence": "the n > 1 code of this entry runs with 2 / 3 / 8 logical ranks on one GPU against an RCCL test double "
+                               "(tests/test_gpu_multirank.py); real RCCL with more than one rank has only run where this line has n_gpus > 1",
             "device_kernel_ms": [round(float(np.mean([st["device_kernel_ms"][i] for st in steps_st])), 3) for i in range(world)],
             "collective_ms": round(float(np.mean([st["collective_ms"] for st in steps_st])), 3),
             "call_wall_ms": round(float(np.mean([st["wall_ms"] for st in steps_st])), 3)}
@@ -490,10 +502,15 @@ def main():
             del ref_buf
         result["parity"] = par
 
-    # outside the timed region, for the record: what it took to get the scene onto the GPU(s) (device BVH build)
-    result["scene_setup"] = {"device_bvh_build_ms": round(float(bvh_ms), 2), "device_bvh_call_s": round(t2 - t1, 2), "scene_upload_s": round(t3 - t2, 2),
-                             "note": "BVH::build (bvh.rs:13-161) on the GPU, identical node array and triangle order (tests/test_gpu_more.py); "
-                                     "the call includes the 1.1 GB host <-> device copies of the triangle array"}
+    # outside the timed region, for the record: what it took to get the scene onto the GPU(s)
+    result["scene_setup"] = {"entry": "mipt_multi_create_from_triangles" if single else "mipt_scene_create_from_triangles",
+                             "call_s": round(t2 - t1, 3), "total_ms": round(setup_info["total_ms"], 1),
+                             "upload_ms": round(setup_info["upload_ms"], 1), "device_bvh_build_ms": round(setup_info["build_ms"], 2),
+                             "device_layout_ms": round(setup_info["layout_ms"], 2), "replica_ms": replica_ms,
+                             "geometry_bytes": setup_info["geometry_bytes"],
+                             "note": "one call: triangles host -> device once (staged through a pinned ring), BVH::build (bvh.rs:13-161) and the whole "
+                                     "device layout in HBM; identical tree, byte-identical layout to mipt_bvh_build + mipt_scene_create "
+                                     "(tests/test_gpu_scene_device.py, tests/test_gpu_fullsize.py); round 3: 0.44 s + 0.89 s"}
     # ---- N = 1: the in-library multi-GPU path (mipt_render_multi: RCCL communicator + gather / reduce behind the C ABI) ----
     if rank == 0 and world == 1 and not single and not args.no_render_multi:
         try:

@@ -41,7 +41,9 @@ def test_bench_json_contract(built):
     assert "glibc" in r["parity"]["against"]
     assert r["render_multi"]["equals_bench_frame"] is True and r["render_multi"]["n_devices"] == 1 and r["render_multi"]["collective_ms"] > 0
     assert r["value"] > 0 and r["ms_per_step"] > 0
-    assert r["scene_setup"]["device_bvh_build_ms"] > 0 and r["scene_setup"]["scene_upload_s"] >= 0
+    ss = r["scene_setup"]
+    assert ss["entry"] == "mipt_scene_create_from_triangles" and ss["device_bvh_build_ms"] > 0 and ss["device_layout_ms"] > 0 and ss["total_ms"] <= ss["call_s"] * 1e3 + 1
+    assert "RGBA8 epilogue" in r["config"]["workload"]
 
 
 @pytest.mark.gpu

@@ -4,7 +4,6 @@ import collections
 import csv
 import datetime
 import glob
-import hashlib
 import os
 import sys
 
@@ -21,11 +20,10 @@ for d in sorted(glob.glob(out + "/p*/")):
     for dsp in disp[1:] if len(disp) > 1 else disp:          # drop the first (cold) launch
         for n, v in per[dsp].items():
             agg[n].append(v)
-h = hashlib.sha256()
-for f in ("pt_kernel.hip", "pt_device_math.h", "pt_kernel.h", "glibc_flt32_data.h", "mipt_api.cpp", "bvh_build.cpp"):
-    h.update(open(os.path.join("rust_ray_tracing_amd", "csrc", f), "rb").read())
+sys.path.insert(0, os.getcwd())
+from rust_ray_tracing_amd.provenance import kernel_source_sha  # noqa: E402  (no torch, no library load)
 with open(out + "/pmc_summary.csv", "w") as f:
-    f.write(f"# kernel_sha={h.hexdigest()[:16]} date={datetime.date.today().isoformat()} tool=tools/pmc_summary.py command={command} launches=after-1-warm-up\n")
+    f.write(f"# kernel_sha={kernel_source_sha()} date={datetime.date.today().isoformat()} tool=tools/pmc_summary.py command={command} launches=after-1-warm-up\n")
     f.write("kernel,counter,mean_per_launch,launches\n")
     for n, v in sorted(agg.items()):
         f.write(f"{filt.replace(',', ';')},{n},{sum(v) / len(v):.1f},{len(v)}\n")
