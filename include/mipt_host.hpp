@@ -29,8 +29,9 @@ struct RendererOptions {                                   // src/renderer.rs:96
     std::optional<std::string> output_image_path;
     RendererBackend backend = RendererBackend::GPU;
     bool is_realtime = true;
-    // MI355X arm only
-    uint32_t traversal = MIPT_TRAVERSAL_REFERENCE;
+    // MI355X arm only: the recommended traversal (best-hit cull with MIPT_CULL_MARGIN_SAFE: the CPU backend's frame bit for bit,
+    // 1.7x faster).  MIPT_TRAVERSAL_REFERENCE = the CPU backend's own un-culled traversal (ray.rs:69-81).
+    uint32_t traversal = MIPT_TRAVERSAL_CULLED;
     int device_id = 0;
 };
 
@@ -61,6 +62,17 @@ struct Texture {                                           // src/texture.rs:4-1
 
 class Scene {                                              // src/scene.rs:12-19
   public:
+    Scene() = default;
+    // The device residency (replicas + communicators) is NOT shared between copies: a copy starts without one and creates its own on
+    // its first render_node -- two copies rendering from two threads must not meet in one MiptMulti's buffers and streams.
+    Scene(const Scene &o) : tris(o.tris), materials(o.materials), textures(o.textures), bvh_nodes(o.bvh_nodes), camera(o.camera) {}
+    Scene &operator=(const Scene &o) {
+        if (this != &o) { tris = o.tris; materials = o.materials; textures = o.textures; bvh_nodes = o.bvh_nodes; camera = o.camera; release_device(); }
+        return *this;
+    }
+    Scene(Scene &&) = default;
+    Scene &operator=(Scene &&) = default;
+
     std::vector<MiptTriangle> tris;
     std::vector<std::pair<std::string, MiptMaterial>> materials;   // name -> Material, in material-id order
     std::vector<Texture> textures;
@@ -74,6 +86,7 @@ class Scene {                                              // src/scene.rs:12-19
         const char **names = nullptr;
         mipt_obj_get(obj, &d, &names);
         Scene s;
+        s.release_device();
         s.tris.assign(d.tris, d.tris + d.n_tris);
         s.bvh_nodes.assign(d.nodes, d.nodes + d.n_nodes);
         for (uint32_t i = 0; i < d.n_materials; i++) s.materials.emplace_back(names[i], d.materials[i]);
@@ -90,8 +103,8 @@ class Scene {                                              // src/scene.rs:12-19
 
     // Device residency for Renderer::render_node: the per-device replicas, streams and RCCL communicators (MiptMulti) are
     // created on first use and kept -- like the wgpu backend's State, built once in State::new (gpu.rs:96-118) -- so a
-    // second frame costs no upload and no ncclCommInitAll.  Call release_device() after changing tris / bvh_nodes /
-    // materials / textures (the camera is passed per frame and needs no re-upload).
+    // second frame costs no upload and no ncclCommInitAll.  build_bvh() invalidates it; after editing the public tris / bvh_nodes /
+    // materials / textures directly call release_device() (the camera is passed per frame and needs no re-upload).
     void release_device() const { multi_.reset(); multi_devices_ = -1; }
     MiptMulti *node_handle(int n_devices) const {
         if (multi_ && multi_devices_ == n_devices) return multi_.get();
@@ -119,6 +132,7 @@ class Scene {                                              // src/scene.rs:12-19
         uint32_t n = 0;
         if (mipt_bvh_build(tris.data(), (uint32_t)tris.size(), bvh_nodes.data(), (uint32_t)bvh_nodes.size(), &n, threads) != MIPT_OK) n = 0;
         bvh_nodes.resize(n);
+        release_device();                                  // the replicas hold the old tree and triangle order
     }
 };
 
