@@ -297,6 +297,10 @@ MIPT_API int mipt_bvh_build(MiptTriangle *tris, uint32_t n_tris, MiptNode *nodes
  * and, optionally, the material names in material-id order. */
 typedef struct MiptObj MiptObj;
 MIPT_API int  mipt_obj_load(const char *path, MiptObj **out);
+/* The same without BVH::build (scene.rs:80): triangles in file order, no nodes (mipt_obj_get: nodes = NULL, n_nodes = 0) -- the input
+ * of mipt_scene_create_from_triangles, which builds the tree on the GPU.  (A 10 M-triangle file: parsing takes seconds on 16 cores,
+ * the host BVH build ten times that.) */
+MIPT_API int  mipt_obj_load_triangles(const char *path, MiptObj **out);
 MIPT_API int  mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc_out, const char ***material_names_out);
 MIPT_API void mipt_obj_free(MiptObj *obj);
 

@@ -98,7 +98,7 @@ EXPORTS = [
     "mipt_texture_load", "mipt_texture_free", "mipt_image_save_png",
     "mipt_multi_create", "mipt_multi_destroy", "mipt_multi_device_count", "mipt_render_multi",
     "mipt_render_multi_device", "mipt_multi_root_device", "mipt_multi_device_stats",
-    "mipt_scene_create_from_triangles", "mipt_scene_get_bvh", "mipt_scene_info", "mipt_multi_create_from_triangles", "mipt_multi_scene",
+    "mipt_scene_create_from_triangles", "mipt_scene_get_bvh", "mipt_scene_info", "mipt_multi_create_from_triangles", "mipt_multi_scene", "mipt_obj_load_triangles",
 ]
 
 _lib = None
@@ -157,6 +157,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.mipt_device_count.restype = C.c_int
     lib.mipt_obj_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.mipt_obj_load.restype = C.c_int
+    lib.mipt_obj_load_triangles.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.mipt_obj_load_triangles.restype = C.c_int
     lib.mipt_obj_free.argtypes = [vp]
     lib.mipt_obj_free.restype = None
     lib.mipt_obj_get.argtypes = [vp, C.POINTER(MiptSceneDesc), C.POINTER(C.POINTER(C.c_char_p))]
@@ -218,7 +220,7 @@ def load_multitest() -> C.CDLL:
 DIAG_LIB_PATH = os.path.join(_HERE, "libmipt_diag.so")
 DIAG_EXPORTS = ["mipt_debug_eval", "mipt_debug_eval_range", "mipt_diag_last_error",
                 "mipt_internal_pair_order", "mipt_internal_pair_order_top", "mipt_internal_tri_slots",
-                "mipt_diag_scene_sizes", "mipt_diag_scene_read", "mipt_diag_scene_hash"]
+                "mipt_diag_scene_sizes", "mipt_diag_scene_read", "mipt_diag_scene_hash", "mipt_diag_write_obj"]
 _diag = None
 
 
@@ -252,6 +254,8 @@ def load_diag() -> C.CDLL:
     lib.mipt_diag_scene_read.restype = C.c_int
     lib.mipt_diag_scene_hash.argtypes = [vp, C.POINTER(C.c_uint64 * 2)]
     lib.mipt_diag_scene_hash.restype = C.c_int
+    lib.mipt_diag_write_obj.argtypes = [C.c_char_p, vp, C.c_uint64, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]
+    lib.mipt_diag_write_obj.restype = C.c_int
     _diag = lib
     return lib
 

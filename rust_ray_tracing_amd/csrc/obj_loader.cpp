@@ -13,7 +13,13 @@
 //    other formats are reported and skipped.
 #include "../../include/mipt.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +30,7 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mipt_internal.h"   // mipt_internal_set_error (mipt_api.cpp) feeds mipt_last_error()
@@ -39,7 +46,10 @@ bool decode_bmp(const std::string &path, uint32_t *w, uint32_t *h, std::vector<u
 
 namespace {
 
-struct ObjTri { size_t pos[3] = {0, 0, 0}, tex[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}; uint32_t material_id = 0; }; // obj.rs:344-350
+// obj.rs:344-350.  Indices as u32, saturated: an index >= 2^32 - 1 names a vertex no array can hold, i.e. "missing" (scene.rs:50-65 reads
+// missing indices as zeros) exactly like the usize it stands for.  While a chunk is parsed material_id holds 1 + the chunk's usemtl
+// event that governs the face (0 = the material active at the chunk's start).
+struct ObjTri { uint32_t pos[3] = {0, 0, 0}, tex[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}; uint32_t material_id = 0; };
 
 struct Tex { uint32_t w = 0, h = 0, hash = 0; std::vector<uint8_t> rgba; };
 
@@ -244,70 +254,256 @@ int load_mtl(MiptObj *obj, const std::string &path) {               // obj.rs:13
     return MIPT_OK;
 }
 
-bool read_index(const std::string &s, size_t *out) {                 // obj.rs:355-362
-    if (s.empty()) return false;
+// ---- the OBJ body: chunked, multi-threaded, allocation-free per line -------------------------------------------------------------
+// The file is mapped and cut into chunks at line ends; worker threads parse chunks into private arrays that are concatenated in file
+// order afterwards.  Nothing a line means depends on an earlier line except the active material (obj.rs:76-92), which is resolved in
+// a sequential pass over the chunks' usemtl events; indices are absolute (negative = relative ones are refused like the reference's
+// panic), so faces need no vertex counts.  The arrays are the ones the line-by-line loader produced (tests/test_obj_loader.py compares
+// them byte for byte on the 1 M-triangle scene and on every small fixture).
+struct Span {
+    const char *b, *e;
+    size_t size() const { return (size_t)(e - b); }
+    std::string str() const { return std::string(b, e); }
+};
+inline bool is_ws(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }          // isspace in the "C" locale
+
+// str::parse::<f32> as strtof does it (the line loader's parse_f32), with a fast path for plain decimals: mantissa < 2^53 and
+// |exponent| <= 22 make `m * 10^k` / `m / 10^k` ONE correctly rounded double operation (both operands exact), and the double rounds
+// to the same float as the decimal itself unless it sits exactly on the midpoint of two floats -- detected, and left to strtof
+// together with everything unusual (hex, inf, nan, > 19 digits, huge exponents, junk).
+bool parse_f32_slow(const char *b, const char *e, float *out) {
+    char buf[128];
+    std::string big;
+    const char *z;
+    if ((size_t)(e - b) < sizeof buf) { memcpy(buf, b, (size_t)(e - b)); buf[e - b] = '\0'; z = buf; }
+    else { big.assign(b, e); z = big.c_str(); }
+    if (!*z || memchr(b, '\0', (size_t)(e - b))) return false;
     char *end = nullptr;
-    long v = strtol(s.c_str(), &end, 10);
-    if (end == s.c_str() || *end != '\0') return false;
-    v -= 1;
-    if (v < 0) return false;                                         // reference: panic on negative indices
-    *out = (size_t)v;
+    const float v = strtof(z, &end);
+    if (end == z || *end != '\0') return false;
+    *out = v;
+    return true;
+}
+inline bool parse_f32_span(const char *b, const char *e, float *out) {
+    static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *p = b;
+    if (p == e) return false;
+    bool neg = false;
+    if (*p == '+' || *p == '-') { neg = *p == '-'; p++; }
+    uint64_t m = 0;
+    int sig = 0, frac = 0;
+    bool any = false, slow = false;
+    for (; p < e && *p >= '0' && *p <= '9'; p++) { any = true; if (sig < 19) { m = m * 10 + (uint64_t)(*p - '0'); if (m) sig++; } else slow = true; }
+    if (p < e && *p == '.') {
+        p++;
+        for (; p < e && *p >= '0' && *p <= '9'; p++) { any = true; if (sig < 19) { m = m * 10 + (uint64_t)(*p - '0'); if (m) sig++; frac++; } else slow = true; }
+    }
+    int ex = 0;
+    if (any && p < e && (*p == 'e' || *p == 'E')) {
+        const char *q = p + 1;
+        bool eneg = false;
+        if (q < e && (*q == '+' || *q == '-')) { eneg = *q == '-'; q++; }
+        if (q == e || *q < '0' || *q > '9') slow = true;
+        for (; q < e && *q >= '0' && *q <= '9'; q++) { if (ex < 100000) ex = ex * 10 + (*q - '0'); }
+        if (eneg) ex = -ex;
+        p = q;
+    }
+    if (!any || slow || p != e) return parse_f32_slow(b, e, out);
+    if (m == 0) { *out = neg ? -0.0f : 0.0f; return true; }
+    const int e10 = ex - frac;
+    if (m >= (1ull << 53) || e10 < -22 || e10 > 22) return parse_f32_slow(b, e, out);
+    const double d = e10 < 0 ? (double)m / p10[-e10] : (double)m * p10[e10];
+    const float f = (float)d;
+    if ((double)f != d) {
+        const float g = nextafterf(f, d > (double)f ? INFINITY : -INFINITY);
+        if (fabs(d - (double)f) == fabs((double)g - d)) return parse_f32_slow(b, e, out);     // on a float midpoint: the decimal decides
+    }
+    *out = neg ? -f : f;
     return true;
 }
 
-bool tri_from_groups(const std::string g[3], ObjTri *t) {            // obj.rs:364-400
+// obj.rs:355-362 through strtol's eyes: [+-]digits, all of the token; value - 1 must not be negative
+inline bool read_index(const char *b, const char *e, uint32_t *out) {
+    const char *p = b;
+    if (p == e) return false;
+    bool neg = false;
+    if (*p == '+' || *p == '-') { neg = *p == '-'; p++; }
+    if (p == e) return false;
+    uint64_t v = 0;
+    int nd = 0;
+    for (; p < e && *p >= '0' && *p <= '9'; p++) { if (nd < 18) { v = v * 10 + (uint64_t)(*p - '0'); nd++; } else v = ~0ull >> 1; }
+    if (p != e) return false;
+    if (neg || v == 0) return false;                                     // v - 1 < 0: the reference panics on negative (relative) indices
+    v -= 1;
+    *out = v >= 0xffffffffull ? 0xffffffffu : (uint32_t)v;
+    return true;
+}
+inline const char *find2(const char *b, const char *e, char c) {         // first "cc" in [b, e)
+    for (const char *p = b; p + 1 < e; p++) if (p[0] == c && p[1] == c) return p;
+    return nullptr;
+}
+bool tri_from_groups(const Span g[3], ObjTri *t) {                       // obj.rs:364-400
     for (int gi = 0; gi < 3; gi++) {
-        const std::string &grp = g[gi];
-        size_t dbl = grp.find("//");
-        if (dbl != std::string::npos) {
-            if (!read_index(grp.substr(0, dbl), &t->pos[gi])) return false;
-            std::string rest = grp.substr(dbl + 2);
-            size_t again = rest.find("//");
-            if (!read_index(again == std::string::npos ? rest : rest.substr(0, again), &t->nrm[gi])) return false;
-        } else if (grp.find('/') != std::string::npos) {
-            std::vector<std::string> parts;
-            size_t start = 0;
-            for (;;) {
-                size_t sl = grp.find('/', start);
-                parts.push_back(grp.substr(start, sl == std::string::npos ? std::string::npos : sl - start));
-                if (sl == std::string::npos) break;
-                start = sl + 1;
-            }
-            if (parts.size() == 2) {
-                if (!read_index(parts[0], &t->pos[gi]) || !read_index(parts[1], &t->tex[gi])) return false;
-            } else if (parts.size() == 3) {
-                if (!read_index(parts[0], &t->pos[gi]) || !read_index(parts[1], &t->tex[gi]) || !read_index(parts[2], &t->nrm[gi])) return false;
-            }
+        const char *b = g[gi].b, *e = g[gi].e;
+        if (const char *dbl = find2(b, e, '/')) {
+            if (!read_index(b, dbl, &t->pos[gi])) return false;
+            const char *rest = dbl + 2, *again = find2(rest, e, '/');
+            if (!read_index(rest, again ? again : e, &t->nrm[gi])) return false;
+        } else if (const char *s1 = (const char *)memchr(b, '/', (size_t)(e - b))) {
+            const char *s2 = (const char *)memchr(s1 + 1, '/', (size_t)(e - s1 - 1));
+            if (!s2) {
+                if (!read_index(b, s1, &t->pos[gi]) || !read_index(s1 + 1, e, &t->tex[gi])) return false;
+            } else if (!memchr(s2 + 1, '/', (size_t)(e - s2 - 1))) {
+                if (!read_index(b, s1, &t->pos[gi]) || !read_index(s1 + 1, s2, &t->tex[gi]) || !read_index(s2 + 1, e, &t->nrm[gi])) return false;
+            }                                                            // four or more parts: the reference's match has no arm -- indices stay 0
         } else {
-            if (!read_index(grp, &t->pos[gi])) return false;
+            if (!read_index(b, e, &t->pos[gi])) return false;
         }
     }
     return true;
 }
 
-bool tris_from_face(const std::string &s, std::vector<ObjTri> *out) { // obj.rs:352-436
-    std::vector<std::string> g = split_ws(s);
-    auto emit = [&](size_t a, size_t b, size_t c) {
-        std::string grp[3] = {g[a], g[b], g[c]};
-        ObjTri t;
-        if (!tri_from_groups(grp, &t)) return false;
-        out->push_back(t);
+struct Chunk {
+    const char *b = nullptr, *e = nullptr;
+    std::vector<std::array<float, 3>> pos, nrm;
+    std::vector<std::array<float, 2>> tex;
+    std::vector<ObjTri> tris;
+    std::vector<int64_t> events;        // one per usemtl line: the material id it names, -1 = no such material (the active one stays)
+    std::vector<std::string> unknown;   // names of those, for the log lines
+    bool failed = false;
+    std::string err;
+};
+
+// one line of the body (obj.rs:54-104); returns false with c->err set on the errors the reference panics on
+bool parse_line(Chunk *c, const char *lb, const char *le, bool has_mtl, const std::vector<std::string> &material_names, std::vector<Span> *groups) {
+    const char *p = lb;
+    while (p < le && is_ws(*p)) p++;
+    if (p == le) return true;
+    const char *q = p;
+    while (q < le && !is_ws(*q)) q++;
+    const size_t tl = (size_t)(q - p);
+    auto next_tok = [&](const char **tb, const char **te) -> bool {
+        while (q < le && is_ws(*q)) q++;
+        if (q == le) return false;
+        *tb = q;
+        while (q < le && !is_ws(*q)) q++;
+        *te = q;
         return true;
     };
-    if (g.size() == 3) return emit(0, 1, 2);
-    if (g.size() == 4) return emit(0, 1, 3) && emit(1, 2, 3);        // quad split, obj.rs:412-419
-    if (g.size() >= 5) {                                             // n-gon fan, obj.rs:421-432
-        for (size_t i = 0; i + 2 < g.size(); i++) if (!emit(0, i + 1, i + 2)) return false;
+    const bool is_v = tl == 1 && p[0] == 'v', is_vn = tl == 2 && p[0] == 'v' && p[1] == 'n', is_vt = tl == 2 && p[0] == 'v' && p[1] == 't';
+    if (is_v || is_vn || is_vt) {
+        float d[3] = {0.0f, 0.0f, 0.0f};
+        const int cap = is_vt ? 2 : 3;
+        int n = 0;
+        const char *tb, *te;
+        while (next_tok(&tb, &te)) {
+            if (n == cap) {
+                c->err = is_vt ? "'vt' line with more than 2 components (the reference panics): " + std::string(lb, le)
+                               : "'" + std::string(p, p + tl) + "' line with more than 3 components (the reference panics): " + std::string(lb, le);
+                return false;
+            }
+            if (!parse_f32_span(tb, te, &d[n])) { c->err = "bad number in: " + std::string(lb, le); return false; }
+            n++;
+        }
+        if (is_vt) c->tex.push_back({d[0], d[1]});
+        else (is_v ? c->pos : c->nrm).push_back({d[0], d[1], d[2]});
         return true;
     }
-    return false;
+    if (tl == 6 && memcmp(p, "usemtl", 6) == 0) {
+        if (!has_mtl) return true;
+        if ((size_t)(le - lb) < 7 || memcmp(lb, "usemtl ", 7) != 0) { c->err = "malformed usemtl line: " + std::string(lb, le); return false; }
+        const size_t nl = (size_t)(le - lb) - 7;
+        int64_t id = -1;
+        for (size_t i = 0; i < material_names.size(); i++)
+            if (material_names[i].size() == nl && memcmp(material_names[i].data(), lb + 7, nl) == 0) { id = (int64_t)i; break; }
+        if (id < 0) c->unknown.emplace_back(lb + 7, le);
+        c->events.push_back(id);
+        return true;
+    }
+    if (tl == 1 && p[0] == 'f') {
+        if ((size_t)(le - lb) < 2 || lb[0] != 'f' || lb[1] != ' ') { c->err = "malformed face line: " + std::string(lb, le); return false; }
+        groups->clear();
+        q = lb + 2;
+        const char *tb, *te;
+        while (next_tok(&tb, &te)) groups->push_back(Span{tb, te});
+        const std::vector<Span> &g = *groups;
+        bool ok = true;
+        auto emit = [&](size_t a, size_t b, size_t cc) {
+            const Span grp[3] = {g[a], g[b], g[cc]};
+            ObjTri t;
+            if (!tri_from_groups(grp, &t)) return false;
+            t.material_id = (uint32_t)c->events.size();                  // 0 = inherited from before this chunk
+            c->tris.push_back(t);
+            return true;
+        };
+        if (g.size() == 3) ok = emit(0, 1, 2);
+        else if (g.size() == 4) ok = emit(0, 1, 3) && emit(1, 2, 3);      // quad split, obj.rs:412-419
+        else if (g.size() >= 5) { for (size_t i = 0; i + 2 < g.size() && ok; i++) ok = emit(0, i + 1, i + 2); }   // n-gon fan, obj.rs:421-432
+        else ok = false;
+        if (!ok) { c->err = "malformed face (bad, negative or <3 indices): " + std::string(lb, le); return false; }
+        return true;
+    }
+    return true;
+}
+
+void parse_chunk(Chunk *c, bool has_mtl, const std::vector<std::string> &material_names) {
+    std::vector<Span> groups;
+    const size_t bytes = (size_t)(c->e - c->b);
+    c->pos.reserve(bytes / 96); c->tris.reserve(bytes / 160);
+    const char *lb = c->b;
+    while (lb < c->e) {
+        const char *nl = (const char *)memchr(lb, '\n', (size_t)(c->e - lb));
+        const char *le = nl ? nl : c->e;
+        const char *te = le;
+        if (nl && te > lb && te[-1] == '\r') te--;                        // lines() strips "\n" or "\r\n" (a bare CR at the end of the file stays)
+        if (!parse_line(c, lb, te, has_mtl, material_names, &groups)) { c->failed = true; return; }
+        lb = nl ? nl + 1 : c->e;
+    }
+}
+
+struct Mapped {                                                          // read-only view of a file
+    const char *data = nullptr;
+    size_t size = 0;
+    bool mapped = false;
+    std::string fallback;
+    ~Mapped() { if (mapped) munmap((void *)data, size); }
+    bool open(const std::string &path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); return false; }
+        size = (size_t)st.st_size;
+        if (size == 0) { close(fd); data = ""; return true; }
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            (void)madvise(m, size, MADV_SEQUENTIAL);
+            data = (const char *)m; mapped = true; close(fd); return true;
+        }
+        fallback.resize(size);                                           // e.g. a pipe or a filesystem without mmap
+        size_t got = 0;
+        while (got < size) { const ssize_t r = read(fd, &fallback[got], size - got); if (r <= 0) break; got += (size_t)r; }
+        close(fd);
+        if (got != size) return false;
+        data = fallback.data();
+        return true;
+    }
+};
+
+template <class F> void run_parallel(size_t n_items, unsigned threads, F body) {      // body(item) for every item, dynamic schedule
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n_items) return; body(i); } };
+    std::vector<std::thread> th;
+    try { for (unsigned t = 1; t < threads && t < n_items; t++) th.emplace_back(work); }
+    catch (const std::exception &) {}                                    // fewer helpers: the caller works through the rest
+    work();
+    for (auto &x : th) x.join();
 }
 
 } // namespace
 
 extern "C" {
 
-static int obj_load_impl(const char *path_c, MiptObj **out) {
+static int obj_load_impl(const char *path_c, MiptObj **out, bool build_bvh) {
     if (!path_c || !out) return fail("mipt_obj_load: null argument");
     *out = nullptr;
     const std::string path = path_c;
@@ -318,14 +514,25 @@ static int obj_load_impl(const char *path_c, MiptObj **out) {
         std::string fmt = dot == std::string::npos ? path : path.substr(dot + 1);
         if (fmt != "obj") return fail("Unsupported scene format '" + fmt + "' at path '" + path + "'");
     }
-    std::vector<std::string> lines;
-    if (!read_lines(path, &lines)) return fail("could not read '" + path + "'");
+    Mapped file;
+    if (!file.open(path)) return fail("could not read '" + path + "'");
+    const char *const fb = file.data, *const fe = file.data + file.size;
     std::unique_ptr<MiptObj> obj(new MiptObj);
     bool has_mtl = false;
-    for (const std::string &l : lines) {                             // obj.rs:27-52
-        size_t i = 0;
-        while (i < l.size() && isspace((unsigned char)l[i])) i++;
-        if (l.compare(i, 6, "mtllib") == 0) {
+    {   // obj.rs:27-52: the FIRST line whose first word starts with "mtllib" names the material library
+        const char *p = fb;
+        while (p < fe) {
+            const char *hit = (const char *)memmem(p, (size_t)(fe - p), "mtllib", 6);
+            if (!hit) break;
+            const char *lb = hit;
+            while (lb > fb && lb[-1] != '\n') lb--;
+            bool first_word = true;
+            for (const char *c = lb; c < hit; c++) if (!is_ws(*c)) { first_word = false; break; }
+            if (!first_word) { p = hit + 6; continue; }
+            const char *le = (const char *)memchr(hit, '\n', (size_t)(fe - hit));
+            if (!le) le = fe;
+            if (le > lb && le[-1] == '\r') le--;
+            const std::string l(lb, le);
             if (!starts_with(l, "mtllib ")) return fail("malformed mtllib line: " + l);
             int rc = load_mtl(obj.get(), resource_path(path, l.substr(7)));
             if (rc) return rc;
@@ -339,76 +546,108 @@ static int obj_load_impl(const char *path_c, MiptObj **out) {
         obj->material_names.push_back("default_material");
         obj->materials.push_back(m);
     }
-    std::vector<std::array<float, 3>> positions, normals;
-    std::vector<std::array<float, 2>> tex_coords;
-    std::vector<ObjTri> otris;
-    uint32_t active_material = 0;
-    for (const std::string &line : lines) {                          // obj.rs:54-104
-        std::vector<std::string> tok = split_ws(line);
-        if (tok.empty()) continue;
-        const std::string &p = tok[0];
-        if (p == "v" || p == "vn") {
-            std::array<float, 3> d = {0, 0, 0};
-            if (tok.size() - 1 > 3) return fail("'" + p + "' line with more than 3 components (the reference panics): " + line);
-            for (size_t i = 1; i < tok.size(); i++) if (!parse_f32(tok[i], &d[i - 1])) return fail("bad number in: " + line);
-            (p == "v" ? positions : normals).push_back(d);
-        } else if (p == "vt") {
-            std::array<float, 2> d = {0, 0};
-            if (tok.size() - 1 > 2) return fail("'vt' line with more than 2 components (the reference panics): " + line);
-            for (size_t i = 1; i < tok.size(); i++) if (!parse_f32(tok[i], &d[i - 1])) return fail("bad number in: " + line);
-            tex_coords.push_back(d);
-        } else if (p == "usemtl") {
-            if (has_mtl) {
-                if (!starts_with(line, "usemtl ")) return fail("malformed usemtl line: " + line);
-                const std::string name = line.substr(7);
-                bool found = false;
-                for (size_t i = 0; i < obj->material_names.size(); i++)
-                    if (obj->material_names[i] == name) { active_material = (uint32_t)i; found = true; break; }
-                if (!found) fprintf(stderr, "[mipt] material '%s' doesn't exist; keeping the active one\n", name.c_str());
-            }
-        } else if (p == "f") {
-            if (!starts_with(line, "f ")) return fail("malformed face line: " + line);
-            std::vector<ObjTri> ts;
-            if (!tris_from_face(line.substr(2), &ts)) return fail("malformed face (bad, negative or <3 indices): " + line);
-            for (ObjTri &t : ts) { t.material_id = active_material; otris.push_back(t); }
+    // ---- the body, in chunks cut at line ends ----
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads == 0) threads = 1;
+    if (threads > 16) threads = 16;
+    const size_t want_chunks = file.size < ((size_t)1 << 20) ? 1 : (size_t)threads * 4;
+    std::vector<Chunk> chunks;
+    {
+        const char *p = fb;
+        const size_t step = file.size / want_chunks + 1;
+        while (p < fe) {
+            const char *q = (size_t)(fe - p) > step ? p + step : fe;
+            if (q < fe) { const char *nl = (const char *)memchr(q, '\n', (size_t)(fe - q)); q = nl ? nl + 1 : fe; }
+            Chunk c;
+            c.b = p; c.e = q;
+            chunks.push_back(std::move(c));
+            p = q;
         }
     }
-    if (normals.empty()) {                                           // flat normals, obj.rs:106-120
-        for (size_t i = 0; i < otris.size(); i++) {
-            ObjTri &t = otris[i];
-            for (int k = 0; k < 3; k++) if (t.pos[k] >= positions.size()) return fail("face references a missing vertex");
-            const auto &v1 = positions[t.pos[0]], &v2 = positions[t.pos[1]], &v3 = positions[t.pos[2]];
-            const float ux = v2[0] - v1[0], uy = v2[1] - v1[1], uz = v2[2] - v1[2];
-            const float vx = v3[0] - v1[0], vy = v3[1] - v1[1], vz = v3[2] - v1[2];
-            const float cx = (uy * vz) - (uz * vy), cy = (uz * vx) - (ux * vz), cz = (ux * vy) - (uy * vx);
-            const float len = sqrtf((cx * cx) + (cy * cy) + (cz * cz));
-            normals.push_back({cx / len, cy / len, cz / len});
-            t.nrm[0] = t.nrm[1] = t.nrm[2] = i;
+    run_parallel(chunks.size(), threads, [&](size_t i) { parse_chunk(&chunks[i], has_mtl, obj->material_names); });
+    for (const Chunk &c : chunks) {                                      // the first error in file order, as a line-by-line reader meets it
+        for (const std::string &name : c.unknown) fprintf(stderr, "[mipt] material '%s' doesn't exist; keeping the active one\n", name.c_str());
+        if (c.failed) return fail(c.err);
+    }
+    // ---- concatenate in file order; resolve the active material across chunks (obj.rs:76-92) ----
+    std::vector<size_t> o_pos(chunks.size() + 1, 0), o_nrm(chunks.size() + 1, 0), o_tex(chunks.size() + 1, 0), o_tri(chunks.size() + 1, 0);
+    std::vector<uint32_t> start_material(chunks.size(), 0);
+    {
+        uint32_t active = 0;
+        for (size_t i = 0; i < chunks.size(); i++) {
+            o_pos[i + 1] = o_pos[i] + chunks[i].pos.size(); o_nrm[i + 1] = o_nrm[i] + chunks[i].nrm.size();
+            o_tex[i + 1] = o_tex[i] + chunks[i].tex.size(); o_tri[i + 1] = o_tri[i] + chunks[i].tris.size();
+            start_material[i] = active;
+            for (int64_t &ev : chunks[i].events) { if (ev >= 0) active = (uint32_t)ev; ev = (int64_t)active; }   // event -> the material active after it
         }
+    }
+    if (o_tri.back() > 0xffffffffull) return fail("'" + path + "' holds more than 2^32 triangles");
+    std::vector<std::array<float, 3>> positions(o_pos.back()), normals(o_nrm.back());
+    std::vector<std::array<float, 2>> tex_coords(o_tex.back());
+    std::vector<ObjTri> otris(o_tri.back());
+    run_parallel(chunks.size(), threads, [&](size_t i) {
+        Chunk &c = chunks[i];
+        if (!c.pos.empty()) memcpy(&positions[o_pos[i]], c.pos.data(), c.pos.size() * sizeof c.pos[0]);
+        if (!c.nrm.empty()) memcpy(&normals[o_nrm[i]], c.nrm.data(), c.nrm.size() * sizeof c.nrm[0]);
+        if (!c.tex.empty()) memcpy(&tex_coords[o_tex[i]], c.tex.data(), c.tex.size() * sizeof c.tex[0]);
+        for (size_t k = 0; k < c.tris.size(); k++) {
+            ObjTri t = c.tris[k];
+            t.material_id = t.material_id == 0 ? start_material[i] : (uint32_t)c.events[t.material_id - 1];
+            otris[o_tri[i] + k] = t;
+        }
+        std::vector<std::array<float, 3>>().swap(c.pos); std::vector<std::array<float, 3>>().swap(c.nrm);
+        std::vector<std::array<float, 2>>().swap(c.tex); std::vector<ObjTri>().swap(c.tris);
+    });
+    const size_t n_slices = otris.size() < 4096 ? 1 : (size_t)threads * 4;
+    auto slice = [&](size_t i, size_t *b2, size_t *e2) { *b2 = otris.size() * i / n_slices; *e2 = otris.size() * (i + 1) / n_slices; };
+    if (normals.empty()) {                                           // flat normals, obj.rs:106-120: triangle i gets normal i
+        for (const ObjTri &t : otris)
+            for (int k = 0; k < 3; k++) if (t.pos[k] >= positions.size()) return fail("face references a missing vertex");
+        normals.resize(otris.size());
+        run_parallel(n_slices, threads, [&](size_t si) {
+            size_t b2, e2;
+            slice(si, &b2, &e2);
+            for (size_t i = b2; i < e2; i++) {
+                ObjTri &t = otris[i];
+                const auto &v1 = positions[t.pos[0]], &v2 = positions[t.pos[1]], &v3 = positions[t.pos[2]];
+                const float ux = v2[0] - v1[0], uy = v2[1] - v1[1], uz = v2[2] - v1[2];
+                const float vx = v3[0] - v1[0], vy = v3[1] - v1[1], vz = v3[2] - v1[2];
+                const float cx = (uy * vz) - (uz * vy), cy = (uz * vx) - (ux * vz), cz = (ux * vy) - (uy * vx);
+                const float len = sqrtf((cx * cx) + (cy * cy) + (cz * cz));
+                normals[i] = {cx / len, cy / len, cz / len};
+                t.nrm[0] = t.nrm[1] = t.nrm[2] = i >= 0xffffffffull ? 0xffffffffu : (uint32_t)i;
+            }
+        });
     }
     if (otris.empty()) return fail("'" + path + "' contains no faces (the reference panics in BVH::build)");
     // impl From<OBJ> for Scene (scene.rs:44-85): missing indices read as zeros
     obj->tris.resize(otris.size());
-    for (size_t i = 0; i < otris.size(); i++) {
-        MiptTriangle &dst = obj->tris[i];
-        memset(&dst, 0, sizeof dst);
-        for (int k = 0; k < 3; k++) {
+    run_parallel(n_slices, threads, [&](size_t si) {
+        size_t b2, e2;
+        slice(si, &b2, &e2);
+        for (size_t i = b2; i < e2; i++) {
+            MiptTriangle &dst = obj->tris[i];
+            memset(&dst, 0, sizeof dst);
             const ObjTri &t = otris[i];
-            std::array<float, 3> P = {0, 0, 0}, N = {0, 0, 0};
-            std::array<float, 2> T = {0, 0};
-            if (t.pos[k] < positions.size()) P = positions[t.pos[k]];
-            if (t.tex[k] < tex_coords.size()) T = tex_coords[t.tex[k]];
-            if (t.nrm[k] < normals.size()) N = normals[t.nrm[k]];
-            dst.vertices[k].position = {P[0], P[1], P[2]}; dst.vertices[k].tex_coord_x = T[0];
-            dst.vertices[k].normal = {N[0], N[1], N[2]}; dst.vertices[k].tex_coord_y = T[1];
+            for (int k = 0; k < 3; k++) {
+                std::array<float, 3> P = {0, 0, 0}, N = {0, 0, 0};
+                std::array<float, 2> T = {0, 0};
+                if (t.pos[k] < positions.size()) P = positions[t.pos[k]];
+                if (t.tex[k] < tex_coords.size()) T = tex_coords[t.tex[k]];
+                if (t.nrm[k] < normals.size()) N = normals[t.nrm[k]];
+                dst.vertices[k].position = {P[0], P[1], P[2]}; dst.vertices[k].tex_coord_x = T[0];
+                dst.vertices[k].normal = {N[0], N[1], N[2]}; dst.vertices[k].tex_coord_y = T[1];
+            }
+            dst.material_id = t.material_id;
         }
-        dst.material_id = otris[i].material_id;
+    });
+    if (build_bvh) {                                                 // BVH::build(&mut scene), scene.rs:80
+        obj->nodes.resize(2 * obj->tris.size());
+        uint32_t n_nodes = 0;
+        int rc = mipt_bvh_build(obj->tris.data(), (uint32_t)obj->tris.size(), obj->nodes.data(), (uint32_t)obj->nodes.size(), &n_nodes, 0);
+        if (rc) return fail("BVH::build failed");
+        obj->nodes.resize(n_nodes);
     }
-    obj->nodes.resize(2 * obj->tris.size());
-    uint32_t n_nodes = 0;
-    int rc = mipt_bvh_build(obj->tris.data(), (uint32_t)obj->tris.size(), obj->nodes.data(), (uint32_t)obj->nodes.size(), &n_nodes, 0);
-    if (rc) return fail("BVH::build failed");
-    obj->nodes.resize(n_nodes);
     for (const Tex &t : obj->textures) obj->tex_desc.push_back({t.w, t.h, t.rgba.data()});
     for (const std::string &s : obj->material_names) obj->name_ptrs.push_back(s.c_str());
     *out = obj.release();
@@ -418,7 +657,7 @@ static int obj_load_impl(const char *path_c, MiptObj **out) {
 int mipt_obj_get(MiptObj *obj, MiptSceneDesc *desc, const char ***material_names) {
     if (!obj || !desc) return fail("mipt_obj_get: null argument");
     desc->tris = obj->tris.data(); desc->n_tris = (uint32_t)obj->tris.size();
-    desc->nodes = obj->nodes.data(); desc->n_nodes = (uint32_t)obj->nodes.size();
+    desc->nodes = obj->nodes.empty() ? nullptr : obj->nodes.data(); desc->n_nodes = (uint32_t)obj->nodes.size();   // empty: mipt_obj_load_triangles
     desc->materials = obj->materials.data(); desc->n_materials = (uint32_t)obj->materials.size();
     desc->textures = obj->tex_desc.data(); desc->n_textures = (uint32_t)obj->tex_desc.size();
     if (material_names) *material_names = obj->name_ptrs.data();
@@ -458,7 +697,8 @@ static int image_save_png_impl(const char *path, uint32_t width, uint32_t height
     try { return call; }                                                                  \
     catch (const std::bad_alloc &) { return fail("out of host memory"); }                 \
     catch (const std::exception &e) { return fail(std::string("internal error: ") + e.what()); }
-int mipt_obj_load(const char *path, MiptObj **out) { MIPT_NO_THROW(obj_load_impl(path, out)) }
+int mipt_obj_load(const char *path, MiptObj **out) { MIPT_NO_THROW(obj_load_impl(path, out, true)) }
+int mipt_obj_load_triangles(const char *path, MiptObj **out) { MIPT_NO_THROW(obj_load_impl(path, out, false)) }
 int mipt_texture_load(const char *path, MiptImage **out, MiptTexture *desc_out, uint32_t *hash_out) { MIPT_NO_THROW(texture_load_impl(path, out, desc_out, hash_out)) }
 int mipt_image_save_png(const char *path, uint32_t width, uint32_t height, uint32_t bits_per_sample, const void *rgba) {
     MIPT_NO_THROW(image_save_png_impl(path, width, height, bits_per_sample, rgba))

@@ -114,10 +114,12 @@ class Scene:  # scene.rs:12-19
 
     # -- construction ------------------------------------------------------------------------
     @staticmethod
-    def load(path: str) -> Optional["Scene"]:  # scene.rs:22-36
+    def load(path: str, build_bvh: bool = True) -> Optional["Scene"]:  # scene.rs:22-36
+        """``build_bvh=False``: OBJ::load + From<OBJ> without the BVH::build at scene.rs:80 (mipt_obj_load_triangles) -- triangles in file
+        order for ``upload_from_triangles``, which builds the tree on the GPU."""
         lib = L.load()
         obj = C.c_void_p()
-        rc = lib.mipt_obj_load(path.encode(), C.byref(obj))
+        rc = (lib.mipt_obj_load if build_bvh else lib.mipt_obj_load_triangles)(os.fsencode(path), C.byref(obj))
         if rc != 0:
             log_error(lib.mipt_last_error().decode())
             return None
@@ -127,7 +129,8 @@ class Scene:  # scene.rs:12-19
             L.check(lib.mipt_obj_get(obj, C.byref(desc), C.byref(names)), "mipt_obj_get")
             sc = Scene()
             sc.tris = np.ctypeslib.as_array(C.cast(desc.tris, C.POINTER(C.c_uint8)), (desc.n_tris * 112,)).copy().view(L.TRIANGLE)
-            sc.bvh_nodes = np.ctypeslib.as_array(C.cast(desc.nodes, C.POINTER(C.c_uint8)), (desc.n_nodes * 32,)).copy().view(L.NODE)
+            if desc.n_nodes:
+                sc.bvh_nodes = np.ctypeslib.as_array(C.cast(desc.nodes, C.POINTER(C.c_uint8)), (desc.n_nodes * 32,)).copy().view(L.NODE)
             mats = np.ctypeslib.as_array(C.cast(desc.materials, C.POINTER(C.c_uint8)), (desc.n_materials * 80,)).copy().view(L.MATERIAL)
             for i in range(desc.n_materials):
                 sc.materials[names[i].decode()] = mats[i].copy()

@@ -151,6 +151,52 @@ def write_cornell_obj(directory: str) -> str:
     return path
 
 
+def write_obj(directory: str, name: str, tris: np.ndarray, mats, texs=()) -> str:
+    """Writes a scene as <name>.obj + <name>.mtl + <name>_tex<i>.png and returns the .obj path: the on-disk form the reference loads
+    (src/loader/obj.rs).  Triangles go out in array order through libmipt_diag.so's writer (shortest round-trip decimals, so
+    mipt_obj_load returns `tris` bit for bit); materials keep their names (a dict) or are named material_<id>, written in id order with every MTL key the
+    loader reads (obj.rs:150-257); textures as 8-bit RGBA PNGs through mipt_image_save_png (rows flipped back: Texture::load flips)."""
+    import ctypes as C
+    from . import _lib as L
+    os.makedirs(directory, exist_ok=True)
+    lib, diag = L.load(), L.load_diag()
+    tex_files = []
+    for i, t in enumerate(texs):
+        t = np.ascontiguousarray(np.asarray(t, dtype=np.uint8)[::-1])
+        fn = f"{name}_tex{i}.png"
+        L.check(lib.mipt_image_save_png(os.path.join(directory, fn).encode(), t.shape[1], t.shape[0], 8, L.ptr(t)), "mipt_image_save_png")
+        tex_files.append(fn)
+    if isinstance(mats, dict):
+        mat_names = list(mats.keys())
+        mats = list(mats.values())
+    else:
+        mat_names = [f"material_{i}" for i in range(len(mats))]
+    mats = [np.asarray(m, dtype=MATERIAL).reshape(()) for m in mats]
+
+    def num(x):
+        return repr(float(np.float32(x)))
+
+    with open(os.path.join(directory, name + ".mtl"), "w") as f:
+        for i, m in enumerate(mats):
+            f.write(f"newmtl {mat_names[i]}\n")
+            for key, field in (("Kd", "base_color"), ("Ks", "specular_tint"), ("Ke", "emission")):
+                f.write(f"{key} {num(m[field][0])} {num(m[field][1])} {num(m[field][2])}\n")
+            for key, field in (("Ni", "ior"), ("Pr", "roughness"), ("Pm", "metallic"), ("Tf", "transmission"), ("d", "transparency")):
+                f.write(f"{key} {num(m[field])}\n")
+            for key, field in (("map_Kd", "base_color_tex_id"), ("map_d", "transparency_tex_id"), ("map_Pr", "roughness_tex_id"),
+                               ("map_Pm", "metallic_tex_id"), ("map_Ke", "emission_tex_id"), ("map_Bump", "normal_tex_id")):
+                if int(m[field]) != NO_TEXTURE:
+                    f.write(f"{key} {tex_files[int(m[field])]}\n")
+            f.write("\n")
+    tris = np.ascontiguousarray(tris, dtype=TRIANGLE)
+    names = (C.c_char_p * max(len(mats), 1))(*[n.encode() for n in mat_names])
+    path = os.path.join(directory, name + ".obj")
+    rc = diag.mipt_diag_write_obj(path.encode(), L.ptr(tris), len(tris), (name + ".mtl").encode(), names, len(mats))
+    if rc != 0:
+        raise OSError(f"mipt_diag_write_obj({path}) failed with {rc}")
+    return path
+
+
 def cornell_box():
     """The same box as arrays (quad split (0,1,3),(1,2,3) as obj.rs:412-419)."""
     names = list(_CORNELL_MTL.keys())

@@ -32,6 +32,41 @@ int main(int argc, char **argv) {
     for (const char *name : {"cornell.obj", "t.obj", "missing.obj", "neg.obj"}) {
         if (mipt_obj_load((dir + "/" + name).c_str(), &obj) == MIPT_OK) { ok++; mipt_obj_free(obj); } else bad++;
     }
+    // 1b. the chunked, multi-threaded OBJ parser (csrc/obj_loader.cpp) on a file big enough for several chunks (> 1 MB) -- intact, then
+    // truncated at random places and with random bytes flipped: it must return a status or a scene, never touch bad memory or race
+    int obj_ok = 0, obj_bad = 0;
+    {
+        std::string text = "mtllib t.mtl\n";
+        std::mt19937 r2(11);
+        std::uniform_real_distribution<float> u(-5.f, 5.f);
+        char line[256];
+        size_t nv = 0;
+        while (text.size() < (size_t)3 << 20) {
+            for (int k = 0; k < 4; k++) { snprintf(line, sizeof line, "v %.9g %.9g %g\nvt %g %g\nvn %g %g %g\r\n", u(r2), u(r2), u(r2), u(r2), u(r2), u(r2), u(r2), u(r2)); text += line; nv++; }
+            if (r2() % 7 == 0) text += r2() % 2 ? "usemtl a\n" : "usemtl nosuch\n";
+            const size_t a = 1 + r2() % nv, b = 1 + r2() % nv, c = 1 + r2() % nv, d = 1 + r2() % nv, e = 1 + r2() % nv;
+            switch (r2() % 5) {
+            case 0: snprintf(line, sizeof line, "f %zu %zu %zu\n", a, b, c); break;
+            case 1: snprintf(line, sizeof line, "f %zu/%zu %zu/%zu %zu/%zu %zu/%zu\n", a, a, b, b, c, c, d, d); break;
+            case 2: snprintf(line, sizeof line, "f %zu//%zu %zu//%zu %zu//%zu\n", a, a, b, b, c, c); break;
+            case 3: snprintf(line, sizeof line, "f %zu/%zu/%zu %zu/%zu/%zu %zu/%zu/%zu %zu/%zu/%zu %zu/%zu/%zu\n", a, a, a, b, b, b, c, c, c, d, d, d, e, e, e); break;
+            default: snprintf(line, sizeof line, "# comment\n\nf   %zu\t%zu %zu  \n", a, b, c); break;
+            }
+            text += line;
+        }
+        for (int it = 0; it < 40; it++) {
+            std::string m = text;
+            if (it == 1) m += "  f 1 2 3\n";                                                                // a face line must start with "f ": refused
+            else if (it >= 2 && it % 2 == 0) m.resize(r2() % (text.size() + 1));
+            else if (it >= 2) for (int k = 0; k < 1 + (int)(r2() % 8); k++) m[r2() % m.size()] ^= (char)(1u << (r2() % 8));
+            const std::string p = dir + "/big.obj";
+            { std::ofstream o(p, std::ios::binary); o.write(m.data(), (std::streamsize)m.size()); }
+            const int rc = it % 3 ? mipt_obj_load_triangles(p.c_str(), &obj) : mipt_obj_load(p.c_str(), &obj);
+            if (rc == MIPT_OK) { obj_ok++; mipt_obj_free(obj); } else obj_bad++;
+            if (it == 0 && rc != MIPT_OK) return 13;                                                        // the intact 3 MB text loads (several chunks, threads)
+            if (it == 1 && rc == MIPT_OK) return 14;
+        }
+    }
     // 2. PNG decoder under mutation: truncations and bit flips must fail cleanly or decode, never touch bad memory
     std::ifstream f(png, std::ios::binary);
     std::vector<uint8_t> good((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -96,6 +131,7 @@ int main(int argc, char **argv) {
                     if (slot[nodes[j].first_tri_or_child + q] != slot[nodes[j].first_tri_or_child] + q) return 12;
         }
     }
+    printf("big obj: %d loaded / %d rejected\n", obj_ok, obj_bad);
     printf("sanitize_host ok: loader %d ok / %d rejected, png %d decoded / %d rejected, jpeg+tga+bmp %d decoded / %d rejected\n", ok, bad, decoded, rejected,
            jdecoded, jrejected);
     return 0;

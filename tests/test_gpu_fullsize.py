@@ -8,6 +8,7 @@ configs[4]: ~10 M tris, 4096x4096, 1024 spp sharded by samples over 8 ranks -- h
             un-normalised partial sum must equal the oracle's on a strided sample, bit for bit.
 The scene is the seeded atrium stand-in (no assets ship with the reference)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -20,6 +21,8 @@ def atrium10m(rrt):
     from rust_ray_tracing_amd import synth
     tris, mats, texs, cam = synth.atrium_scene(n_target=10_000_000, tex_size=1024)
     sc = rrt.Scene.from_arrays(tris, mats, texs, build_bvh=False)
+    sc.tris_in_generator_order = tris            # (test_obj_file_to_pixels writes them out; sc.tris is reordered by the fetch below)
+    sc.generator_materials = mats
     del tris
     # triangles up once, BVH::build + device layout in HBM (identical tree and layout to the host path: tests/test_gpu_scene_device.py
     # and test_device_resident_setup_at_full_size below); the Scene is left as BVH::build leaves it (nodes + reordered triangles)
@@ -66,6 +69,44 @@ def test_device_resident_setup_at_full_size(rrt, atrium10m):
         print(f"frame crc {crc_dev:08x}; host path: layout {hi['layout_ms']:.0f} ms + upload {hi['upload_ms']:.0f} ms")
     finally:
         host.release()
+
+
+def test_obj_file_to_pixels(rrt, atrium10m, tmp_path):
+    """BASELINE configs 2-4 name OBJ files (reference src/main.rs:21,36): the 10 M-triangle scene written as .obj + .mtl + PNGs, parsed by
+    the chunked loader (mipt_obj_load_triangles, no host BVH build), built and laid out on the GPU, rendered at the metric's
+    configuration -- the same frame, bit for bit, as the array path's."""
+    import shutil
+    import time
+    import zlib
+    from rust_ray_tracing_amd import _lib as L
+    from rust_ray_tracing_amd import synth
+    sc = atrium10m
+    if shutil.disk_usage(str(tmp_path)).free < 8e9:
+        pytest.skip("needs ~4 GB of scratch space for the OBJ file")
+    t0 = time.time()
+    path = synth.write_obj(str(tmp_path), "atrium10m", sc.tris_in_generator_order, sc.generator_materials, sc.textures)
+    t1 = time.time()
+    size = os.path.getsize(path)
+    loaded = rrt.Scene.load(path, build_bvh=False)
+    t2 = time.time()
+    assert loaded is not None and len(loaded.tris) == len(sc.tris) and len(loaded.bvh_nodes) == 0
+    assert loaded.tris.tobytes() == np.ascontiguousarray(sc.tris_in_generator_order).tobytes()
+    os.remove(path)
+    loaded.upload_from_triangles(0)
+    t3 = time.time()
+    loaded.camera = sc.camera
+    w, h, spp, depth = 1920, 1080, 8, 64
+    opt = rrt.make_options(w, h, spp, depth, traversal=L.TRAVERSAL_CULLED)
+    try:
+        f_obj, _ = _device_render(rrt, loaded, opt, w * h * 3)
+        f_arr, _ = _device_render(rrt, sc, opt, w * h * 3)
+        crc_obj = zlib.crc32(f_obj.cpu().numpy().tobytes()) & 0xFFFFFFFF
+        crc_arr = zlib.crc32(f_arr.cpu().numpy().tobytes()) & 0xFFFFFFFF
+        print(f"OBJ on-ramp: file {size / 1e9:.2f} GB written in {t1 - t0:.1f} s; Scene.load (parse + expand, incl. the Python copies) {t2 - t1:.1f} s; "
+              f"device setup {loaded.info()['total_ms']:.0f} ms; frame crc {crc_obj:08x}")
+        assert crc_obj == crc_arr
+    finally:
+        loaded.release()
 
 
 def _device_render(rrt, sc, opt, n_floats):
