@@ -328,7 +328,8 @@ __device__ __forceinline__ bool shade_wgsl(const DevScene &sc, V3 &o, V3 &d, V3 
 #define MIPT_MIN_WAVES_UNCULLED 4      // the CPU backend's un-culled traversal: squeezed into 96 VGPRs it runs 169 ms, at its natural 98 (4 waves) 143 ms
 #endif
 #ifndef MIPT_MIN_WAVES_SHADING1
-#define MIPT_MIN_WAVES_SHADING1 4      // wgpu-shader shading, fully inlined: 128 VGPRs + 56 B scratch (146 without the bound = 3 waves)
+#define MIPT_MIN_WAVES_SHADING1 4      // wgpu-shader shading, fully inlined: 127 VGPRs + 20 B scratch, 21.1 ms on config M (146 VGPRs at 3 waves: 25.2 ms; a non-inlined
+                                       // shade_wgsl: 272 B of call frame, 33.3 ms -- tools/experiments/mode1_noinline_shade_result.txt)
 #endif
 template <bool COUNT, bool CULL, int SHADING>
 __global__ __launch_bounds__(kBlockThreads, SHADING == 0 ? ((CULL && !COUNT) ? MIPT_MIN_WAVES_PER_SIMD : MIPT_MIN_WAVES_UNCULLED) : MIPT_MIN_WAVES_SHADING1) void pt_trace_kernel(DevScene sc, DevParams pr) {
