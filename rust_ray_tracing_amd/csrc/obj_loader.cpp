@@ -5,7 +5,7 @@
 // Behaviour follows the reference statement by statement; where the reference panics
 // (unwrap on a malformed number, negative indices, >3 components, missing .mtl) this loader
 // returns MIPT_ERR_IO with a message instead of unwinding across the C ABI.
-// Deviations, both documented in DESIGN.md:
+// Deviations:
 //  * materials keep INSERTION order (the reference iterates a HashMap, so its material ids are
 //    a per-process random permutation -- src/loader/obj.rs:81-90; results are unaffected);
 //  * map_* texture lines need an image decoder (the `image` crate, not vendored): PNG (png_decode.cpp), JPEG
