@@ -79,16 +79,18 @@ class Scene {                                              // src/scene.rs:12-19
     std::vector<MiptNode> bvh_nodes;                       // scene.bvh.nodes
     Camera camera;
 
-    static std::optional<Scene> load(const std::string &path) {    // src/scene.rs:22-36
+    // build_bvh = false: Scene::load without the BVH::build call at scene.rs:80 -- triangles in file order, bvh_nodes empty; the
+    // MI355X arm then builds the tree on the GPU (Renderer::render -> mipt_scene_create_from_triangles).
+    static std::optional<Scene> load(const std::string &path, bool build_bvh = true) {    // src/scene.rs:22-36
         MiptObj *obj = nullptr;
-        if (mipt_obj_load(path.c_str(), &obj) != MIPT_OK) { log_error(mipt_last_error()); return std::nullopt; }
+        if ((build_bvh ? mipt_obj_load(path.c_str(), &obj) : mipt_obj_load_triangles(path.c_str(), &obj)) != MIPT_OK) { log_error(mipt_last_error()); return std::nullopt; }
         MiptSceneDesc d{};
         const char **names = nullptr;
         mipt_obj_get(obj, &d, &names);
         Scene s;
         s.release_device();
         s.tris.assign(d.tris, d.tris + d.n_tris);
-        s.bvh_nodes.assign(d.nodes, d.nodes + d.n_nodes);
+        if (d.n_nodes) s.bvh_nodes.assign(d.nodes, d.nodes + d.n_nodes);
         for (uint32_t i = 0; i < d.n_materials; i++) s.materials.emplace_back(names[i], d.materials[i]);
         for (uint32_t i = 0; i < d.n_textures; i++) {
             Texture t;
@@ -116,7 +118,7 @@ class Scene {                                              // src/scene.rs:12-19
         MiptSceneDesc d{tris.data(), (uint32_t)tris.size(), bvh_nodes.data(), (uint32_t)bvh_nodes.size(),
                         mats.data(), (uint32_t)mats.size(), texs.data(), (uint32_t)texs.size()};
         MiptMulti *m = nullptr;
-        if (mipt_multi_create(&d, nullptr, n_devices, &m) != MIPT_OK) { log_error(mipt_last_error()); return nullptr; }
+        if ((bvh_nodes.empty() ? mipt_multi_create_from_triangles(&d, nullptr, n_devices, &m) : mipt_multi_create(&d, nullptr, n_devices, &m)) != MIPT_OK) { log_error(mipt_last_error()); return nullptr; }
         multi_ = std::shared_ptr<MiptMulti>(m, [](MiptMulti *p) { mipt_multi_destroy(p); });
         multi_devices_ = n_devices;
         return m;
@@ -162,7 +164,9 @@ class Renderer {                                           // src/renderer.rs:8-
         MiptSceneDesc d{scene.tris.data(), (uint32_t)scene.tris.size(), scene.bvh_nodes.data(), (uint32_t)scene.bvh_nodes.size(),
                         mats.data(), (uint32_t)mats.size(), texs.data(), (uint32_t)texs.size()};
         MiptScene *h = nullptr;
-        if (mipt_scene_create(&d, options.device_id, &h) != MIPT_OK) { log_error(mipt_last_error()); return {}; }
+        // no host-built tree (Scene::load(path, false)): BVH::build + layout on the GPU, identical tree and bytes
+        const int rc_create = scene.bvh_nodes.empty() ? mipt_scene_create_from_triangles(&d, options.device_id, &h) : mipt_scene_create(&d, options.device_id, &h);
+        if (rc_create != MIPT_OK) { log_error(mipt_last_error()); return {}; }
         MiptOptions o{};
         o.width = (uint32_t)options.output_image_dimensions.first; o.height = (uint32_t)options.output_image_dimensions.second;
         o.samples = (uint32_t)options.samples; o.max_ray_depth = (uint32_t)options.max_ray_depth;

@@ -2,10 +2,11 @@
 // triangle order as the host restatement (bvh_build.cpp) and the reference.  SURVEY 8(f) rank 4.
 //
 // Level-synchronous.  Every level's nodes are sorted into classes as they are created (device-side lists, no empty
-// workgroups): > 32768 triangles -> many workgroups per node; 513..32768 -> one 256-thread workgroup per node (the steps
-// below); 17..512 -> one WAVE per node (same steps with wave-level reductions, no block barriers, 4 nodes per workgroup);
-// <= 16 -> one thread per node running the reference's loops as written.
-//   1. centroid range per axis (block reduction; f32 min/max are exact and order-independent)
+// workgroups): > 2 048 triangles -> many workgroups per node, one per 8 192-element chunk (big_* kernels); 17..2 048 -> one WAVE
+// per node with its proxies in registers (three instantiations: <= 64, <= 512, <= 2 048); 9..16 -> one thread per node running the
+// reference's loops as written; <= 8 -> one thread finishes the node's whole subtree.  The steps of a split, in every class:
+//   1. centroid range per axis (f32 min/max are exact and order-independent; for the multi-workgroup path it is a by-product of
+//      the parent's scatter pass, the root's of make_proxies)
 //   2. "first plane the centroid is below" binning with the reference's own plane values and `<` comparisons
 //      (bvh.rs:82-84,147), per-bin boxes and counts through LDS integer atomics on order-preserving keys
 //   3. thread 0 evaluates the 21 candidate costs with the reference's f32 expression (bvh.rs:150-160, incl. the
@@ -15,7 +16,7 @@
 //         k = #(c < pos);  holes h_0<h_1<.. = positions < k holding a ">=" element;  t_0>t_1>.. = positions >= k holding a "<"
 //         "<" at p < k stays;  h_m -> t_(m-1) - 1 (t_-1 = n);  t_m -> h_m;
 //         ">=" at p >= k: p > t_last -> p-1;  p == k -> t_last - 1;  else p-1   (t_last = n when there is no hole)
-//      computed with block-wide scans, written out of place (ping-pong proxy buffers).
+//      computed with block-wide scans (ballots in the wave kernels), written out of place (ping-pong proxy buffers).
 //   5. children appended in pairs; a final pass renumbers the breadth-first tree into the reference's depth-first order
 //      desc(X) = [A, B] ++ desc(A) ++ desc(B) (bvh.rs:131-135) and gathers the 112-byte triangles.
 #include "../../include/mipt.h"
@@ -36,23 +37,30 @@ constexpr int kT = 256;
 constexpr float F32_MAX = FLT_MAX;
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kSubFlag = 0x80000000u;   // BNode::left = kSubFlag | pool index: the node's whole subtree lives in the pool (build_subtree_tiny)
-constexpr uint32_t kBig = 8192;            // nodes with more triangles are split by many workgroups (chunks of kChunk)
+constexpr uint32_t kBig = 2048;            // nodes with more triangles are split by many workgroups (chunks of kChunk).  = kWaveMax: round 3 had a one-workgroup-per-node
+                                           // class in between (2 049..8 192, eight passes behind barriers); once big_scatter lost its scratch traffic the chunked path beat it
 constexpr uint32_t kChunk = 8192;
 constexpr uint32_t kSub = 8;               // nodes this small: ONE thread finishes the whole subtree (build_subtree_tiny)
 constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
 constexpr uint32_t kWaveMax = 2048;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
-enum { CLS_BLOCK = 0, CLS_WAVE = 1, CLS_TINY = 2, CLS_BIG = 3, CLS_SUB = 4, CLS_WAVE_M = 5, CLS_WAVE_L = 6, kClasses = 7 };   // CLS_WAVE: 17..64, _M: 65..512, _L: 513..kWaveMax triangles
+enum { CLS_WAVE = 0, CLS_TINY = 1, CLS_BIG = 2, CLS_SUB = 3, CLS_WAVE_M = 4, CLS_WAVE_L = 5, kClasses = 6 };   // CLS_WAVE: 17..64, _M: 65..512, _L: 513..kWaveMax triangles
 constexpr uint32_t kWaveS = 64u, kWaveM = 512u;
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
 // children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
 struct alignas(128) Pad32 { uint32_t v; uint32_t pad[31]; };        // one counter per 128-B line: atomics on one line serialise, whichever word they hit
-struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][kClasses], pool_alloc, sub_nodes; };   // pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
+struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][kClasses + 1], pool_alloc, sub_nodes; };   // cnt[parity][kClasses]: centroid-range records handed to that level's big nodes (big_finish); pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
 struct Lists { uint32_t *l[2][kClasses]; };
 
 struct alignas(16) Proxy {                                            // 32 B = two 16-B words
     float lo[3]; uint32_t idx; float hi[3]; uint32_t pad;
     __device__ __forceinline__ float c(int a) const { return (lo[a] + hi[a]) / 2.0f; }   // the centroid (scene.rs:125) is re-derived, not stored: a fifth less traffic in every pass
+    // the same for an axis only known at run time: selected from the three, because indexing lo[] / hi[] of a register-resident record
+    // with a variable sends the record to scratch memory
+    __device__ __forceinline__ float cax(int a) const {
+        const float c0 = (lo[0] + hi[0]) / 2.0f, c1 = (lo[1] + hi[1]) / 2.0f, c2 = (lo[2] + hi[2]) / 2.0f;
+        return a == 0 ? c0 : (a == 1 ? c1 : c2);
+    }
 };
 struct BNode {
     float lo[3], hi[3];
@@ -82,7 +90,6 @@ __device__ __forceinline__ float box_area(const float *lo, const float *hi) {   
 // measured 30x slower on the deep levels).  Works under divergence -- only the lanes that reach this point take part.
 __host__ __device__ __forceinline__ uint32_t node_class(uint32_t n) {
     if (n > kBig) return (uint32_t)CLS_BIG;
-    if (n > kWaveMax) return (uint32_t)CLS_BLOCK;
     if (n > kWaveM) return (uint32_t)CLS_WAVE_L;
     if (n > kWaveS) return (uint32_t)CLS_WAVE_M;
     if (n > kTiny) return (uint32_t)CLS_WAVE;
@@ -117,8 +124,8 @@ __device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint
 }
 struct Box3 { float lx, ly, lz, hx, hy, hz; };      // passed by value: keeps the callers' boxes in registers (pointer parameters made
                                                     // the one-thread-per-node kernel's locals spill into 40 KB of LDS per workgroup)
-__device__ __forceinline__ void emit_children(BNode *bn, Ctrl *ctrl, const Lists &ls, uint32_t next_parity, uint32_t node_i,
-                                              Box3 A, Box3 B, uint32_t first, uint32_t k, uint32_t n) {
+__device__ __forceinline__ uint32_t emit_children(BNode *bn, Ctrl *ctrl, const Lists &ls, uint32_t next_parity, uint32_t node_i,
+                                                  Box3 A, Box3 B, uint32_t first, uint32_t k, uint32_t n) {
     const uint32_t base = atomicAdd(&ctrl->n_nodes.v, 2u);
     BNode a, b;
     a.lo[0] = A.lx; a.lo[1] = A.ly; a.lo[2] = A.lz; a.hi[0] = A.hx; a.hi[1] = A.hy; a.hi[2] = A.hz;
@@ -128,6 +135,7 @@ __device__ __forceinline__ void emit_children(BNode *bn, Ctrl *ctrl, const Lists
     bn[base] = a; bn[base + 1] = b;
     bn[node_i].left = base;
     queue_children(ctrl, ls, next_parity, base, k, n - k);
+    return base;
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total = block sum
@@ -146,10 +154,12 @@ __device__ uint32_t block_exscan(uint32_t v, uint32_t *s_warp, uint32_t *total) 
     return add + x - v;
 }
 
+// rootkeys: [0..6) the root box (min keys, max keys), [6..12) the root's centroid range (bvh.rs:67-77 of the first split_node)
 __global__ void make_proxies(const MiptTriangle *tris, uint32_t n, Proxy *px, uint32_t *rootkeys) {
-    __shared__ uint32_t s_lo[3], s_hi[3];
-    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0xffffffffu; s_hi[threadIdx.x] = 0u; }
+    __shared__ uint32_t s_lo[3], s_hi[3], s_clo[3], s_chi[3];
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0xffffffffu; s_hi[threadIdx.x] = 0u; s_clo[threadIdx.x] = 0xffffffffu; s_chi[threadIdx.x] = 0u; }
     __syncthreads();
+    float cmn[3] = {F32_MAX, F32_MAX, F32_MAX}, cmx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};      // fminf / fmaxf skip a NaN centroid, as the reference's loop does
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Proxy p;
         p.idx = i; p.pad = 0u;
@@ -158,11 +168,17 @@ __global__ void make_proxies(const MiptTriangle *tris, uint32_t n, Proxy *px, ui
             for (int v = 0; v < 3; v++) { const float q = (&tris[i].vertices[v].position.x)[a]; mn = fminf(mn, q); mx = fmaxf(mx, q); }
             p.lo[a] = mn; p.hi[a] = mx;                                                 // scene.rs:125: see Proxy::c
             atomicMin(&s_lo[a], fkey(mn)); atomicMax(&s_hi[a], fkey(mx));
+            const float c = (mn + mx) / 2.0f;
+            cmn[a] = fminf(cmn[a], c); cmx[a] = fmaxf(cmx[a], c);
         }
         px[i] = p;
     }
+    for (int a = 0; a < 3; a++) { atomicMin(&s_clo[a], fkey(cmn[a])); atomicMax(&s_chi[a], fkey(cmx[a])); }
     __syncthreads();
-    if (threadIdx.x < 3) { atomicMin(&rootkeys[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&rootkeys[3 + threadIdx.x], s_hi[threadIdx.x]); }
+    if (threadIdx.x < 3) {
+        atomicMin(&rootkeys[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&rootkeys[3 + threadIdx.x], s_hi[threadIdx.x]);
+        atomicMin(&rootkeys[6 + threadIdx.x], s_clo[threadIdx.x]); atomicMax(&rootkeys[9 + threadIdx.x], s_chi[threadIdx.x]);
+    }
 }
 
 __global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
@@ -170,209 +186,6 @@ __global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
     for (int a = 0; a < 3; a++) { r.lo[a] = funkey(rootkeys[a]); r.hi[a] = funkey(rootkeys[3 + a]); }
     r.first = 0; r.n = n; r.left = kNone; r.size = 0; r.dfs = 0; r.base = 1;
     bn[0] = r;
-}
-
-// one workgroup per node of this level's CLS_BLOCK list (kWaveMax < n <= kBig).  (A 1024-thread instantiation for the larger of
-// these nodes was measured: one such workgroup per CU is slower than six of 256 threads, 28.3 vs 27.4 ms.)
-constexpr int kTB = kT;
-__global__ __launch_bounds__(kTB) void build_level(BNode *bn, const uint32_t *__restrict__ list, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
-                                                  uint32_t *hole_pos, uint32_t *tail_pos, Ctrl *ctrl, Lists ls, uint32_t next_parity) {
-    // per axis, per bin: lo.xyz (min keys), hi.xyz (max keys) and the count.  kCopies private copies (thread & 7 picks one,
-    // merged after the pass): with one copy the 64 lanes of a wave pile onto 8 addresses per atomic and serialise.
-    __shared__ uint32_t s_keyc[kCopies][3][8][6];
-    __shared__ uint32_t s_cntc[kCopies][3][8];
-    uint32_t(*s_key)[8][6] = s_keyc[0];
-    uint32_t(*s_cnt)[8] = s_cntc[0];
-    __shared__ uint32_t s_cmin[3], s_cmax[3];
-    __shared__ uint32_t s_ckey[2][6];        // child boxes (L, R)
-    __shared__ uint32_t s_warp[kTB / 64];
-    __shared__ float s_pos[3][8];
-    __shared__ int s_use[3];
-    __shared__ int s_split, s_axis;
-    __shared__ float s_splitpos;
-    __shared__ uint32_t s_k;
-
-    const uint32_t node_i = list[blockIdx.x];
-    const BNode nd = bn[node_i];
-    const uint32_t first = nd.first, n = nd.n, tid = threadIdx.x;
-    const Proxy *in = pin + first;
-    Proxy *out = pout + first;
-
-    // ---- 1. centroid ranges (bvh.rs:67-77; f32::MIN == -f32::MAX) ----
-    if (tid < 3) { s_cmin[tid] = 0xffffffffu; s_cmax[tid] = 0u; }
-    for (uint32_t i = tid; i < kCopies * 144u; i += kTB) (&s_keyc[0][0][0][0])[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
-    for (uint32_t i = tid; i < kCopies * 24u; i += kTB) (&s_cntc[0][0][0])[i] = 0u;
-    if (tid < 12) (&s_ckey[0][0])[tid] = ((tid % 6) < 3) ? 0xffffffffu : 0u;
-    __syncthreads();
-    {
-        float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-        for (uint32_t i = tid; i < n; i += kTB)
-            for (int a = 0; a < 3; a++) { const float c = in[i].c(a); mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c); }
-        for (int a = 0; a < 3; a++) { atomicMin(&s_cmin[a], fkey(mn[a])); atomicMax(&s_cmax[a], fkey(mx[a])); }
-    }
-    __syncthreads();
-    if (tid < 3) {
-        const float cmin = funkey(s_cmin[tid]), cmax = funkey(s_cmax[tid]);
-        s_use[tid] = !(cmin == cmax);                                                   // bvh.rs:78
-        const float scale = (cmax - cmin) / 8.0f;                                       // bvh.rs:82
-        for (int i = 1; i < 8; i++) s_pos[tid][i] = cmin + (float)i * scale;            // bvh.rs:84
-    }
-    __syncthreads();
-    // ---- 2. binning: bin = first plane i (1..7) with c < pos_i, else 8 (stored at i-1) ----
-    for (uint32_t i = tid; i < n; i += kTB) {
-        const Proxy p = in[i];
-        for (int a = 0; a < 3; a++) {
-            if (!s_use[a]) continue;
-            int k = 8;
-            for (int j = 1; j < 8; j++) if (p.c(a) < s_pos[a][j]) { k = j; break; }
-            uint32_t *key = s_keyc[tid & (kCopies - 1u)][a][k - 1];
-            for (int q = 0; q < 3; q++) { lds_min(&key[q], fkey(p.lo[q])); lds_max(&key[3 + q], fkey(p.hi[q])); }
-            atomicAdd(&s_cntc[tid & (kCopies - 1u)][a][k - 1], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid < 144u) {                                   // merge the private copies into copy 0
-        uint32_t v = (&s_keyc[0][0][0][0])[tid];
-        for (uint32_t c = 1; c < kCopies; c++) { const uint32_t w = (&s_keyc[c][0][0][0])[tid]; v = ((tid % 6u) < 3u) ? (w < v ? w : v) : (w > v ? w : v); }
-        (&s_keyc[0][0][0][0])[tid] = v;
-    } else if (tid < 168u) {
-        uint32_t v = 0;
-        for (uint32_t c = 0; c < kCopies; c++) v += (&s_cntc[c][0][0])[tid - 144u];
-        (&s_cntc[0][0][0])[tid - 144u] = v;
-    }
-    __syncthreads();
-    // ---- 3. SAH (bvh.rs:58-97, 138-161) ----
-    if (tid == 0) {
-        const float parent_cost = (float)n * box_area(nd.lo, nd.hi);
-        float best_cost = F32_MAX, best_pos = 0.0f;
-        int best_axis = 0;
-        uint32_t best_k = kNone;                        // #(c < pos) of the winning plane = the bins below it (planes increase with i)
-        for (int a = 0; a < 3; a++) {
-            if (!s_use[a]) continue;
-            float rlo[8][3], rhi[8][3];
-            uint32_t rcnt[8];
-            float alo[3] = {F32_MAX, F32_MAX, F32_MAX}, ahi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-            uint32_t c = 0;
-            for (int k = 7; k >= 0; k--) {
-                for (int q = 0; q < 3; q++) { alo[q] = fminf(alo[q], funkey(s_key[a][k][q])); ahi[q] = fmaxf(ahi[q], funkey(s_key[a][k][3 + q])); }
-                // (an empty bin's untouched keys decode to NaN, which fminf/fmaxf ignore: same as merging Node::default())
-                c += s_cnt[a][k];
-                for (int q = 0; q < 3; q++) { rlo[k][q] = alo[q]; rhi[k][q] = ahi[q]; }
-                rcnt[k] = c;
-            }
-            float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-            uint32_t lc = 0;
-            for (int i = 1; i < 8; i++) {
-                for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(s_key[a][i - 1][q])); lhi[q] = fmaxf(lhi[q], funkey(s_key[a][i - 1][3 + q])); }
-                lc += s_cnt[a][i - 1];
-                const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
-                const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
-                if (split_cost < best_cost) { best_axis = a; best_pos = s_pos[a][i]; best_cost = split_cost; best_k = lc; }
-            }
-        }
-        s_split = !(best_cost >= parent_cost);                                          // bvh.rs:94
-        s_axis = best_axis; s_splitpos = best_pos; s_k = best_k;
-    }
-    __syncthreads();
-    if (!s_split) {                                   // leaf: carry the range over unchanged
-        for (uint32_t i = tid; i < n; i += kTB) out[i] = in[i];
-        return;
-    }
-    const int axis = s_axis;
-    const float pos = s_splitpos;
-    // ---- 4. the partition permutation ----
-    if (s_k == kNone) {                                 // only when no candidate was finite (NaN parent cost): count directly
-        __syncthreads();
-        uint32_t cnt = 0;
-        for (uint32_t i = tid; i < n; i += kTB) cnt += (in[i].c(axis) < pos) ? 1u : 0u;
-        uint32_t tot;
-        (void)block_exscan<kTB / 64>(cnt, s_warp, &tot);
-        if (tid == 0) s_k = tot;
-        __syncthreads();
-    }
-    const uint32_t k = s_k;
-    uint32_t *hp = hole_pos + first, *tp = tail_pos + first;
-    // holes: positions p < k holding ">=", in increasing p  ->  hp[m] = p
-    uint32_t n_holes = 0;
-    for (uint32_t base = 0; base < k; base += kTB) {
-        const uint32_t p = base + tid;
-        const uint32_t f = (p < k && !(in[p].c(axis) < pos)) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
-        if (f) hp[n_holes + r] = p;
-        n_holes += tot;
-    }
-    // tail "<": positions p >= k holding "<", in decreasing p  ->  tp[m] = p
-    uint32_t n_tail = 0;
-    for (uint32_t base = 0; base < n - k; base += kTB) {
-        const uint32_t q = base + tid;                  // q-th position from the end
-        const uint32_t p = n - 1u - q;
-        const uint32_t f = (q < n - k && (in[p].c(axis) < pos)) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
-        if (f) tp[n_tail + r] = p;
-        n_tail += tot;
-    }
-    __threadfence();                                    // hp / tp are read by other threads of this block below
-    __syncthreads();
-    const uint32_t t_last = n_holes ? __hip_atomic_load(&tp[n_holes - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
-    // scatter + child boxes
-    uint32_t hole_rank_base = 0, tail_seen = 0;
-    (void)tail_seen;
-    float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
-    // (a) positions < k: forward, hole rank by scan
-    for (uint32_t base = 0; base < k; base += kTB) {
-        const uint32_t p = base + tid;
-        Proxy e;
-        uint32_t f = 0;
-        if (p < k) { e = in[p]; f = !(e.c(axis) < pos) ? 1u : 0u; }
-        uint32_t tot;
-        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
-        if (p < k) {
-            uint32_t dest;
-            if (!f) dest = p;
-            else {
-                const uint32_t m = hole_rank_base + r;
-                const uint32_t tprev = m ? __hip_atomic_load(&tp[m - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
-                dest = tprev - 1u;
-            }
-            out[dest] = e;
-            const int side = f ? 1 : 0;
-            for (int q = 0; q < 3; q++) { clo[side][q] = fminf(clo[side][q], e.lo[q]); chi[side][q] = fmaxf(chi[side][q], e.hi[q]); }
-        }
-        hole_rank_base += tot;
-    }
-    // (b) positions >= k: from the end, tail rank by scan
-    uint32_t tail_rank_base = 0;
-    for (uint32_t base = 0; base < n - k; base += kTB) {
-        const uint32_t q = base + tid;
-        const uint32_t p = n - 1u - q;
-        Proxy e;
-        uint32_t f = 0;
-        const bool valid = q < n - k;
-        if (valid) { e = in[p]; f = (e.c(axis) < pos) ? 1u : 0u; }
-        uint32_t tot;
-        const uint32_t r = block_exscan<kTB / 64>(f, s_warp, &tot);
-        if (valid) {
-            uint32_t dest;
-            if (f) dest = __hip_atomic_load(&hp[tail_rank_base + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (p > t_last) dest = p - 1u;
-            else dest = (p == k) ? (t_last - 1u) : (p - 1u);
-            out[dest] = e;
-            const int side = f ? 0 : 1;
-            for (int qq = 0; qq < 3; qq++) { clo[side][qq] = fminf(clo[side][qq], e.lo[qq]); chi[side][qq] = fmaxf(chi[side][qq], e.hi[qq]); }
-        }
-        tail_rank_base += tot;
-    }
-    for (int sd = 0; sd < 2; sd++)
-        for (int q = 0; q < 3; q++) { atomicMin(&s_ckey[sd][q], fkey(clo[sd][q])); atomicMax(&s_ckey[sd][3 + q], fkey(chi[sd][q])); }
-    __syncthreads();
-    // ---- 5. children (bvh.rs:115-132) ----
-    if (tid == 0) {
-        const Box3 A{funkey(s_ckey[0][0]), funkey(s_ckey[0][1]), funkey(s_ckey[0][2]), funkey(s_ckey[0][3]), funkey(s_ckey[0][4]), funkey(s_ckey[0][5])};
-        const Box3 B{funkey(s_ckey[1][0]), funkey(s_ckey[1][1]), funkey(s_ckey[1][2]), funkey(s_ckey[1][3]), funkey(s_ckey[1][4]), funkey(s_ckey[1][5])};
-        emit_children(bn, ctrl, ls, next_parity, node_i, A, B, first, k, n);
-    }
 }
 
 // ---- nodes with 17..kWaveMax triangles: one wave64 per node, four nodes per workgroup; the same five steps with wave-level
@@ -572,8 +385,13 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
             Proxy e; e.pad = 0u; e.lo[0] = l0[j]; e.lo[1] = l1[j]; e.lo[2] = l2[j]; e.hi[0] = h0[j]; e.hi[1] = h1[j]; e.hi[2] = h2[j]; e.idx = id[j];
             out[dest] = e;
             const int side = lt ? 0 : 1;
-            clo[side][0] = fminf(clo[side][0], l0[j]); clo[side][1] = fminf(clo[side][1], l1[j]); clo[side][2] = fminf(clo[side][2], l2[j]);
-            chi[side][0] = fmaxf(chi[side][0], h0[j]); chi[side][1] = fmaxf(chi[side][1], h1[j]); chi[side][2] = fmaxf(chi[side][2], h2[j]);
+            if (side) {                                   // (constant indices only: a `[side]` index would send the arrays to scratch)
+                clo[1][0] = fminf(clo[1][0], l0[j]); clo[1][1] = fminf(clo[1][1], l1[j]); clo[1][2] = fminf(clo[1][2], l2[j]);
+                chi[1][0] = fmaxf(chi[1][0], h0[j]); chi[1][1] = fmaxf(chi[1][1], h1[j]); chi[1][2] = fmaxf(chi[1][2], h2[j]);
+            } else {
+                clo[0][0] = fminf(clo[0][0], l0[j]); clo[0][1] = fminf(clo[0][1], l1[j]); clo[0][2] = fminf(clo[0][2], l2[j]);
+                chi[0][0] = fmaxf(chi[0][0], h0[j]); chi[0][1] = fmaxf(chi[0][1], h1[j]); chi[0][2] = fmaxf(chi[0][2], h2[j]);
+            }
         }
         holes_before += (uint32_t)__popcll(mh);
     }
@@ -849,16 +667,22 @@ struct BigState {
     float splitpos;
     uint32_t k, n_holes;
     int k_known;                   // k taken from the bin counts of the winning plane (big_choose); else big_count counts it
-    uint32_t ckey[2][6];
+    int plane;                     // the winning plane's index 1..7 (bins below it hold the "<" elements)
+    uint32_t ckey[2][6];           // child boxes (A, B) as keys
+    uint32_t ccen[2][6];           // child centroid ranges (A, B) as keys: the next level's step 1, gathered by big_scatter
     float lo[3], hi[3];            // node bounds
 };
 struct ChunkInfo { uint32_t big, off, len, hole_cnt, tail_cnt, hole_base, tail_base, pad; };
+struct ChunkBins { uint32_t cnt[3][8]; };   // per chunk: elements per (axis, bin) -- big_bin's by-product, from which big_count2 derives holes / tails without a pass
 
 // One workgroup: a BigState per big node of the level and the chunk table (chunks of a node contiguous, increasing offset),
 // all on the device -- the host only launches (its grids are sized by the bound n_tris / kChunk + nb and the surplus
 // workgroups leave at once).
+// The node's centroid range (bvh.rs:67-77) is already known: the root's from make_proxies, every other big node's from its parent's
+// big_scatter (big_finish left the record index in the node's `dfs` field, which the final renumbering overwrites).  So the planes
+// (bvh.rs:82-84) are computed here and the level needs no pass of its own for them.
 __global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, const uint32_t *ids, uint32_t nb, ChunkInfo *ch,
-                                                uint32_t *chunk_begin, Ctrl *ctrl) {
+                                                uint32_t *chunk_begin, Ctrl *ctrl, const uint32_t *rootkeys, const uint32_t *crange) {
     __shared__ uint32_t s_warp[4];
     uint32_t running = 0;
     for (uint32_t base = 0; base < nb; base += kT) {
@@ -867,13 +691,22 @@ __global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, c
         BNode nd;
         if (j < nb) {
             nd = bn[ids[j]];
-            BigState s;
-            memset(&s, 0, sizeof s);
+            BigState &s = bs[j];                                                         // written in place: a local copy of the 700-byte record lives in scratch
             s.node = ids[j]; s.first = nd.first; s.n = nd.n;
-            for (int a = 0; a < 3; a++) { s.cmin[a] = 0xffffffffu; s.cmax[a] = 0u; s.lo[a] = nd.lo[a]; s.hi[a] = nd.hi[a]; }
-            for (int a = 0; a < 3; a++) for (int k = 0; k < 8; k++) for (int q = 0; q < 6; q++) s.key[a][k][q] = q < 3 ? 0xffffffffu : 0u;
-            for (int sd = 0; sd < 2; sd++) for (int q = 0; q < 6; q++) s.ckey[sd][q] = q < 3 ? 0xffffffffu : 0u;
-            bs[j] = s;
+            s.split = 0; s.axis = 0; s.splitpos = 0.0f; s.k = 0u; s.n_holes = 0u; s.k_known = 0; s.plane = 0;
+            uint32_t cr[6];
+            if (ids[j] == 0u) { for (int q = 0; q < 6; q++) cr[q] = rootkeys[6 + q]; }
+            else { for (int q = 0; q < 6; q++) cr[q] = crange[(size_t)(nd.dfs - 1u) * 6u + (uint32_t)q]; }
+            for (int a = 0; a < 3; a++) {
+                s.cmin[a] = cr[a]; s.cmax[a] = cr[3 + a]; s.lo[a] = nd.lo[a]; s.hi[a] = nd.hi[a];
+                const float cmin = funkey(cr[a]), cmax = funkey(cr[3 + a]);
+                s.use[a] = !(cmin == cmax);                                              // bvh.rs:78
+                const float scale = (cmax - cmin) / 8.0f;                                // bvh.rs:82
+                s.pos[a][0] = 0.0f;
+                for (int i = 1; i < 8; i++) s.pos[a][i] = cmin + (float)i * scale;       // bvh.rs:84
+            }
+            for (int a = 0; a < 3; a++) for (int k = 0; k < 8; k++) { s.cnt[a][k] = 0u; for (int q = 0; q < 6; q++) s.key[a][k][q] = q < 3 ? 0xffffffffu : 0u; }
+            for (int sd = 0; sd < 2; sd++) for (int q = 0; q < 6; q++) { s.ckey[sd][q] = q < 3 ? 0xffffffffu : 0u; s.ccen[sd][q] = q < 3 ? 0xffffffffu : 0u; }
             my_chunks = (nd.n + kChunk - 1u) / kChunk;
         }
         uint32_t tot;
@@ -891,32 +724,7 @@ __global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, c
     }
     if (threadIdx.x == 0) { chunk_begin[nb] = running; ctrl->n_chunks.v = running; }
 }
-__global__ __launch_bounds__(kT) void big_range(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
-    __shared__ uint32_t s_mn[3], s_mx[3];
-    if (blockIdx.x >= ctrl->n_chunks.v) return;
-    const ChunkInfo c = ch[blockIdx.x];
-    BigState *b = bs + c.big;
-    const Proxy *in = pin + b->first + c.off;
-    if (threadIdx.x < 3) { s_mn[threadIdx.x] = 0xffffffffu; s_mx[threadIdx.x] = 0u; }
-    __syncthreads();
-    float mn[3] = {F32_MAX, F32_MAX, F32_MAX}, mx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-    for (uint32_t i = threadIdx.x; i < c.len; i += kT)
-        for (int a = 0; a < 3; a++) { const float v = in[i].c(a); mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
-    for (int a = 0; a < 3; a++) { atomicMin(&s_mn[a], fkey(mn[a])); atomicMax(&s_mx[a], fkey(mx[a])); }
-    __syncthreads();
-    if (threadIdx.x < 3) { atomicMin(&b->cmin[threadIdx.x], s_mn[threadIdx.x]); atomicMax(&b->cmax[threadIdx.x], s_mx[threadIdx.x]); }
-}
-__global__ void big_planes(BigState *bs, uint32_t nb) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nb * 3u) return;
-    BigState *b = bs + j / 3u;
-    const int a = (int)(j % 3u);
-    const float cmin = funkey(b->cmin[a]), cmax = funkey(b->cmax[a]);
-    b->use[a] = !(cmin == cmax);
-    const float scale = (cmax - cmin) / 8.0f;
-    for (int i = 1; i < 8; i++) b->pos[a][i] = cmin + (float)i * scale;
-}
-__global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
+__global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, ChunkBins *cbins, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_keyc[kCopies][3][8][6];
     __shared__ uint32_t s_cntc[kCopies][3][8];
     __shared__ float s_pos[3][8];
@@ -952,6 +760,7 @@ __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch,
         uint32_t v = 0;
         for (uint32_t cc = 0; cc < kCopies; cc++) v += (&s_cntc[cc][0][0])[i];
         if (v) atomicAdd(&(&b->cnt[0][0])[i], v);
+        (&cbins[blockIdx.x].cnt[0][0])[i] = v;
     }
 }
 __global__ void big_choose(BigState *bs, uint32_t nb) {                              // same expression order as build_level step 3
@@ -960,7 +769,7 @@ __global__ void big_choose(BigState *bs, uint32_t nb) {                         
     BigState *b = bs + j;
     const float parent_cost = (float)b->n * box_area(b->lo, b->hi);
     float best_cost = F32_MAX, best_pos = 0.0f;
-    int best_axis = 0;
+    int best_axis = 0, best_plane = 0;
     uint32_t best_k = kNone;
     for (int a = 0; a < 3; a++) {
         if (!b->use[a]) continue;
@@ -981,11 +790,11 @@ __global__ void big_choose(BigState *bs, uint32_t nb) {                         
             lc += b->cnt[a][i - 1];
             const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
             const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
-            if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; best_k = lc; }
+            if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; best_k = lc; best_plane = i; }
         }
     }
     b->split = !(best_cost >= parent_cost);
-    b->axis = best_axis; b->splitpos = best_pos;
+    b->axis = best_axis; b->splitpos = best_pos; b->plane = best_plane;
     b->k_known = best_k != kNone;
     if (b->k_known) b->k = best_k;
 }
@@ -998,23 +807,36 @@ __global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *c
     const Proxy *in = pin + b->first + c.off;
     const int axis = b->axis; const float pos = b->splitpos;
     uint32_t cnt = 0;
-    for (uint32_t i = threadIdx.x; i < c.len; i += kT) cnt += (in[i].c(axis) < pos) ? 1u : 0u;
+    for (uint32_t i = threadIdx.x; i < c.len; i += kT) cnt += (in[i].cax(axis) < pos) ? 1u : 0u;
     uint32_t tot;
     (void)block_exscan(cnt, s_warp, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(&b->k, tot);
 }
-__global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {   // holes / tail-"<" per chunk
+// holes (positions < k holding ">=") and tail "<" (positions >= k holding "<") per chunk.  With k taken from the winning plane's bin
+// counts the chunk's own counts say how many of its elements are "<" (bins below the plane: the planes increase with their index), so
+// a chunk that lies wholly below or above k needs no look at its elements; only the one chunk per node that straddles k is read.
+__global__ __launch_bounds__(kT) void big_count2(BigState *bs, ChunkInfo *ch, const ChunkBins *cbins, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
     if (blockIdx.x >= ctrl->n_chunks.v) return;
     ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
     if (!b->split) return;
-    const Proxy *in = pin + b->first + c.off;
     const int axis = b->axis; const float pos = b->splitpos; const uint32_t k = b->k;
+    if (b->k_known && (c.off + c.len <= k || c.off >= k)) {
+        if (threadIdx.x == 0) {
+            uint32_t less = 0;
+            for (int j = 0; j < b->plane; j++) less += cbins[blockIdx.x].cnt[axis][j];
+            const bool below = c.off + c.len <= k;
+            ch[blockIdx.x].hole_cnt = below ? c.len - less : 0u;
+            ch[blockIdx.x].tail_cnt = below ? 0u : less;
+        }
+        return;
+    }
+    const Proxy *in = pin + b->first + c.off;
     uint32_t holes = 0, tails = 0;
     for (uint32_t i = threadIdx.x; i < c.len; i += kT) {
         const uint32_t p = c.off + i;
-        const bool l = in[i].c(axis) < pos;
+        const bool l = in[i].cax(axis) < pos;
         holes += (p < k && !l) ? 1u : 0u;
         tails += (p >= k && l) ? 1u : 0u;
     }
@@ -1064,7 +886,7 @@ __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkIn
     uint32_t hb = c.hole_base, tb = c.tail_base;
     for (uint32_t base = 0; base < c.len; base += kT) {                 // holes: increasing p
         const uint32_t i = base + threadIdx.x, p = c.off + i;
-        const uint32_t f = (i < c.len && p < k && !(in[i].c(axis) < pos)) ? 1u : 0u;
+        const uint32_t f = (i < c.len && p < k && !(in[i].cax(axis) < pos)) ? 1u : 0u;
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (f) hp[hb + r] = p;
@@ -1073,17 +895,35 @@ __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkIn
     for (uint32_t base = 0; base < c.len; base += kT) {                 // tail "<": decreasing p
         const uint32_t q = base + threadIdx.x;
         const uint32_t i = c.len - 1u - q, p = c.off + i;
-        const uint32_t f = (q < c.len && p >= k && (in[i].c(axis) < pos)) ? 1u : 0u;
+        const uint32_t f = (q < c.len && p >= k && (in[i].cax(axis) < pos)) ? 1u : 0u;
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (f) tp[tb + r] = p;
         tb += tot;
     }
 }
+// box and centroid range of one side of a split, in scalars (an array the compiler cannot prove constant-indexed goes to scratch)
+struct SideAcc {
+    float l0 = F32_MAX, l1 = F32_MAX, l2 = F32_MAX, h0 = -F32_MAX, h1 = -F32_MAX, h2 = -F32_MAX;
+    float cl0 = F32_MAX, cl1 = F32_MAX, cl2 = F32_MAX, ch0 = -F32_MAX, ch1 = -F32_MAX, ch2 = -F32_MAX;
+    __device__ __forceinline__ void add(const Proxy &e) {
+        l0 = fminf(l0, e.lo[0]); l1 = fminf(l1, e.lo[1]); l2 = fminf(l2, e.lo[2]);
+        h0 = fmaxf(h0, e.hi[0]); h1 = fmaxf(h1, e.hi[1]); h2 = fmaxf(h2, e.hi[2]);
+        const float c0 = e.c(0), c1 = e.c(1), c2 = e.c(2);
+        cl0 = fminf(cl0, c0); cl1 = fminf(cl1, c1); cl2 = fminf(cl2, c2);
+        ch0 = fmaxf(ch0, c0); ch1 = fmaxf(ch1, c1); ch2 = fmaxf(ch2, c2);
+    }
+    __device__ __forceinline__ void flush(uint32_t *box_keys, uint32_t *cen_keys) const {       // keys: min xyz, max xyz (LDS)
+        atomicMin(&box_keys[0], fkey(l0)); atomicMin(&box_keys[1], fkey(l1)); atomicMin(&box_keys[2], fkey(l2));
+        atomicMax(&box_keys[3], fkey(h0)); atomicMax(&box_keys[4], fkey(h1)); atomicMax(&box_keys[5], fkey(h2));
+        atomicMin(&cen_keys[0], fkey(cl0)); atomicMin(&cen_keys[1], fkey(cl1)); atomicMin(&cen_keys[2], fkey(cl2));
+        atomicMax(&cen_keys[3], fkey(ch0)); atomicMax(&cen_keys[4], fkey(ch1)); atomicMax(&cen_keys[5], fkey(ch2));
+    }
+};
 __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
                                                   const uint32_t *hole_pos, const uint32_t *tail_pos, const Ctrl *ctrl) {
     __shared__ uint32_t s_warp[4];
-    __shared__ uint32_t s_ckey[2][6];
+    __shared__ uint32_t s_ckey[2][6], s_ccen[2][6];
     if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     BigState *b = bs + c.big;
@@ -1092,25 +932,26 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
     if (!b->split) { for (uint32_t i = threadIdx.x; i < c.len; i += kT) out[c.off + i] = in[i]; return; }
     const uint32_t *hp = hole_pos + b->first, *tp = tail_pos + b->first;
     const int axis = b->axis; const float pos = b->splitpos; const uint32_t k = b->k, n = b->n, n_holes = b->n_holes;
-    if (threadIdx.x < 12) (&s_ckey[0][0])[threadIdx.x] = ((threadIdx.x % 6) < 3) ? 0xffffffffu : 0u;
+    if (threadIdx.x < 12) { (&s_ckey[0][0])[threadIdx.x] = ((threadIdx.x % 6) < 3) ? 0xffffffffu : 0u; (&s_ccen[0][0])[threadIdx.x] = ((threadIdx.x % 6) < 3) ? 0xffffffffu : 0u; }
     __syncthreads();
+    // Child boxes, and the children's centroid ranges (the next level's bvh.rs:67-77: they fall out of this pass, every element's side is
+    // known here).  One accumulator set per side, indexed by constants only -- a `[side]` index would send the arrays to scratch.
+    SideAcc A, B;
     const uint32_t t_last = n_holes ? tp[n_holes - 1u] : n;
-    float clo[2][3] = {{F32_MAX, F32_MAX, F32_MAX}, {F32_MAX, F32_MAX, F32_MAX}}, chi[2][3] = {{-F32_MAX, -F32_MAX, -F32_MAX}, {-F32_MAX, -F32_MAX, -F32_MAX}};
     uint32_t hb = c.hole_base;
     for (uint32_t base = 0; base < c.len; base += kT) {                 // positions < k, increasing
         const uint32_t i = base + threadIdx.x, p = c.off + i;
         const bool valid = i < c.len && p < k;
         Proxy e;
         uint32_t f = 0;
-        if (valid) { e = in[i]; f = !(e.c(axis) < pos) ? 1u : 0u; }
+        if (valid) { e = in[i]; f = !(e.cax(axis) < pos) ? 1u : 0u; }
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (valid) {
             uint32_t dest = p;
             if (f) { const uint32_t m = hb + r; dest = (m ? tp[m - 1u] : n) - 1u; }
             out[dest] = e;
-            const int side = f ? 1 : 0;
-            for (int q = 0; q < 3; q++) { clo[side][q] = fminf(clo[side][q], e.lo[q]); chi[side][q] = fmaxf(chi[side][q], e.hi[q]); }
+            if (f) B.add(e); else A.add(e);
         }
         hb += tot;
     }
@@ -1121,7 +962,7 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
         const bool valid = q < c.len && p >= k;
         Proxy e;
         uint32_t f = 0;
-        if (valid) { e = in[i]; f = (e.c(axis) < pos) ? 1u : 0u; }
+        if (valid) { e = in[i]; f = (e.cax(axis) < pos) ? 1u : 0u; }
         uint32_t tot;
         const uint32_t r = block_exscan(f, s_warp, &tot);
         if (valid) {
@@ -1130,26 +971,37 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
             else if (p > t_last) dest = p - 1u;
             else dest = (p == k) ? (t_last - 1u) : (p - 1u);
             out[dest] = e;
-            const int side = f ? 0 : 1;
-            for (int qq = 0; qq < 3; qq++) { clo[side][qq] = fminf(clo[side][qq], e.lo[qq]); chi[side][qq] = fmaxf(chi[side][qq], e.hi[qq]); }
+            if (f) A.add(e); else B.add(e);
         }
         tb += tot;
     }
-    for (int sd = 0; sd < 2; sd++)
-        for (int q = 0; q < 3; q++) { atomicMin(&s_ckey[sd][q], fkey(clo[sd][q])); atomicMax(&s_ckey[sd][3 + q], fkey(chi[sd][q])); }
+    A.flush(s_ckey[0], s_ccen[0]);
+    B.flush(s_ckey[1], s_ccen[1]);
     __syncthreads();
     if (threadIdx.x < 12) {
         const uint32_t v = (&s_ckey[0][0])[threadIdx.x];
         if ((threadIdx.x % 6) < 3) atomicMin(&(&b->ckey[0][0])[threadIdx.x], v); else atomicMax(&(&b->ckey[0][0])[threadIdx.x], v);
+    } else if (threadIdx.x < 24) {
+        const uint32_t t = threadIdx.x - 12u, v = (&s_ccen[0][0])[t];
+        if ((t % 6) < 3) atomicMin(&(&b->ccen[0][0])[t], v); else atomicMax(&(&b->ccen[0][0])[t], v);
     }
 }
-__global__ void big_finish(const BigState *bs, BNode *bn, Ctrl *ctrl, Lists ls, uint32_t next_parity, uint32_t nb) {
+// crange: the records of the NEXT level's big nodes (one region per level parity, like the work lists)
+__global__ void big_finish(const BigState *bs, BNode *bn, Ctrl *ctrl, Lists ls, uint32_t next_parity, uint32_t nb, uint32_t *crange, uint32_t crange_cap) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nb || !bs[j].split) return;
     const BigState &s = bs[j];
     const Box3 A{funkey(s.ckey[0][0]), funkey(s.ckey[0][1]), funkey(s.ckey[0][2]), funkey(s.ckey[0][3]), funkey(s.ckey[0][4]), funkey(s.ckey[0][5])};
     const Box3 B{funkey(s.ckey[1][0]), funkey(s.ckey[1][1]), funkey(s.ckey[1][2]), funkey(s.ckey[1][3]), funkey(s.ckey[1][4]), funkey(s.ckey[1][5])};
-    emit_children(bn, ctrl, ls, next_parity, s.node, A, B, s.first, s.k, s.n);
+    const uint32_t base = emit_children(bn, ctrl, ls, next_parity, s.node, A, B, s.first, s.k, s.n);
+    const uint32_t cn[2] = {s.k, s.n - s.k};
+    for (uint32_t sd = 0; sd < 2u; sd++) {                              // a child that is big itself starts its level with the range known
+        if (cn[sd] <= kBig) continue;
+        const uint32_t slot = atomicAdd(&ctrl->cnt[next_parity][kClasses].v, 1u);
+        if (slot >= crange_cap) continue;                               // cannot happen: a level holds at most n / kBig big nodes (the host checks the counter all the same)
+        for (int q = 0; q < 6; q++) crange[(size_t)slot * 6u + (uint32_t)q] = s.ccen[sd][q];
+        bn[base + sd].dfs = slot + 1u;
+    }
 }
 
 __global__ void sizes_level(BNode *bn, uint32_t begin, uint32_t end) {              // bottom-up: |desc(X)|
@@ -1221,17 +1073,18 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     MiptNode *d_nodes = nullptr;
     uint32_t *d_order = nullptr;
     PoolNode *d_pool = nullptr;
-    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr;
+    uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr, *d_crange = nullptr;
     Ctrl *d_ctrl = nullptr, *h_ctrl = nullptr;
     BigState *d_big = nullptr;
     ChunkInfo *d_chunks = nullptr;
+    ChunkBins *d_cbins = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t sb = nullptr, sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, block, wave, tiny) touch disjoint nodes: let them overlap
+    hipStream_t sw = nullptr, sw2 = nullptr, sw3 = nullptr, st = nullptr, sg = nullptr, ss = nullptr;   // the per-level kernels (big path, the three wave kernels, tiny, sub) touch disjoint nodes: let them overlap
     auto cleanup = [&]() {
-        hipStream_t all[] = {sb, sw, sw2, sw3, st, sg, ss};
+        hipStream_t all[] = {sw, sw2, sw3, st, sg, ss};
         for (hipStream_t x : all) if (x) (void)hipStreamDestroy(x);
-        void *p[] = {d_px[0], d_px[1], d_bn, d_nodes, d_order, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_lists};
+        void *p[] = {d_px[0], d_px[1], d_bn, d_nodes, d_order, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_cbins, d_crange, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
         if (h_ctrl) (void)hipHostFree(h_ctrl);
         if (e0) (void)hipEventDestroy(e0);
@@ -1262,21 +1115,22 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         }
         ls.l[pa][CLS_BIG] = d_lists + 2 * (size_t)(kClasses - 1) * list_cap + (size_t)pa * big_cap;
     }
-    HIP_TRY(hipMalloc((void **)&d_root, 24));
+    HIP_TRY(hipMalloc((void **)&d_root, 48));
+    HIP_TRY(hipMalloc((void **)&d_cbins, (size_t)chunk_cap * sizeof(ChunkBins)));
+    HIP_TRY(hipMalloc((void **)&d_crange, 2 * (size_t)big_cap * 6 * 4));
     HIP_TRY(hipMalloc((void **)&d_cbeg, (size_t)(big_cap + 1) * 4));
     HIP_TRY(hipMalloc((void **)&d_big, (size_t)big_cap * sizeof(BigState)));
     HIP_TRY(hipMalloc((void **)&d_chunks, (size_t)chunk_cap * sizeof(ChunkInfo)));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipStreamCreate(&sb));                          // blocking streams: ordered against the null stream's copies / launches
-    HIP_TRY(hipStreamCreate(&sw));
+    HIP_TRY(hipStreamCreate(&sw));                          // blocking streams: ordered against the null stream's copies / launches
     HIP_TRY(hipStreamCreate(&sw2));
     HIP_TRY(hipStreamCreate(&sw3));
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
-    const uint32_t root_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    HIP_TRY(hipMemcpy(d_root, root_init, 24, hipMemcpyHostToDevice));
+    const uint32_t root_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIP_TRY(hipMemcpy(d_root, root_init, 48, hipMemcpyHostToDevice));
     Ctrl hc;
     memset(&hc, 0, sizeof hc);
     hc.n_nodes.v = 1u;
@@ -1298,25 +1152,23 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         lvl_begin.push_back(begin);
         const uint32_t nb = hc.cnt[parity][CLS_BIG].v;
         if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk);
-                                                        // its own stream: these 11 launches overlap the level's block / wave / tiny kernels
+                                                        // its own stream: these 9 launches overlap the level's block / wave / tiny kernels
             const uint32_t nc = n_tris / kChunk + nb;   // bound on sum(ceil(n_j / kChunk)); the real count lives in ctrl->n_chunks
             if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             const dim3 gb((nb + 63) / 64), tb(64);
-            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl);
-            hipLaunchKernelGGL(big_range, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_planes, dim3((nb * 3 + 63) / 64), tb, 0, sg, d_big, nb);
-            hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            if (hc.cnt[parity][kClasses].v > big_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
+            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl, d_root, d_crange + (size_t)parity * big_cap * 6);
+            hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_cbins, d_px[cur], d_ctrl);
             hipLaunchKernelGGL(big_choose, gb, tb, 0, sg, d_big, nb);
             hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_cbins, d_px[cur], d_ctrl);
             hipLaunchKernelGGL(big_scan, dim3(nb), dim3(64), 0, sg, d_big, d_chunks, d_cbeg, nb);
             hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_hp, d_tp, d_ctrl);
             hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
-            hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb);
+            hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb, d_crange + (size_t)(parity ^ 1u) * big_cap * 6, big_cap);
         }
-        const uint32_t nblk = hc.cnt[parity][CLS_BLOCK].v, ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
+        const uint32_t ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
         const uint32_t nws = hc.cnt[parity][CLS_WAVE].v, nwm = hc.cnt[parity][CLS_WAVE_M].v, nwl = hc.cnt[parity][CLS_WAVE_L].v;
-        if (nblk) hipLaunchKernelGGL(build_level, dim3(nblk), dim3(kTB), 0, sb, d_bn, ls.l[parity][CLS_BLOCK], d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl, ls, parity ^ 1u);
         if (nwl) hipLaunchKernelGGL((build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>), dim3((nwl + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes), dim3(64 * kWaveBigNodes), 0, sw3,
                                     d_bn, ls.l[parity][CLS_WAVE_L], nwl, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
         if (nwm) hipLaunchKernelGGL((build_level_wave<kWaveS, kWaveM, 8, 4>), dim3((nwm + 7u) / 8u), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE_M], nwm, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
@@ -1328,8 +1180,8 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         hc = *h_ctrl;
         const uint32_t total = hc.n_nodes.v;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        for (int c = 0; c < kClasses; c++) hc.cnt[parity][c].v = 0u;   // this level's lists are consumed: reset for level + 2
-        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, kClasses * sizeof(Pad32), nullptr));           // stream-ordered, no host round trip
+        for (int c = 0; c <= kClasses; c++) hc.cnt[parity][c].v = 0u;   // this level's lists (and its centroid-range records) are consumed: reset for level + 2
+        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, (kClasses + 1) * sizeof(Pad32), nullptr));     // stream-ordered, no host round trip
         begin = end; end = total; cur ^= 1; parity ^= 1u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }

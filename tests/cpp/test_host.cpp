@@ -63,6 +63,13 @@ int main(int argc, char **argv) {
     const std::vector<uint8_t> px_node2 = r->render_node(*scene);                    // ... so a second frame re-uses them
     CHECK(scene->node_handle(0) == kept && px_node2 == px_node);
     scene->release_device();
+    {   // the same file without the host BVH build: the tree is built on the GPU, the bytes are the same
+        auto raw = Scene::load(obj, false);
+        CHECK(raw && raw->tris.size() == 12 && raw->bvh_nodes.empty());
+        raw->set_camera(cam);
+        CHECK(r->render(*raw) == px);
+        CHECK(r->render_node(*raw) == px);
+    }
     printf("host mirror (gpu) ok: config 1 RGBA8 identical to the oracle\n");
     return 0;
 }
