@@ -2,9 +2,9 @@
 // triangle order as the host restatement (bvh_build.cpp) and the reference.  SURVEY 8(f) rank 4.
 //
 // Level-synchronous.  Every level's nodes are sorted into classes as they are created (device-side lists, no empty
-// workgroups): > 2 048 triangles -> many workgroups per node, one per 8 192-element chunk (big_* kernels); 17..2 048 -> one WAVE
-// per node with its proxies in registers (three instantiations: <= 64, <= 512, <= 2 048); 9..16 -> one thread per node running the
-// reference's loops as written; <= 8 -> one thread finishes the node's whole subtree.  The steps of a split, in every class:
+// workgroups): > 2 048 triangles -> many workgroups per node, one per 8 192-element chunk (big_* kernels); 9..2 048 -> one WAVE
+// per node with its proxies in registers (three instantiations: <= 64, <= 512, <= 2 048); 5..8 -> one thread per node running the
+// reference's loops as written; <= 4 -> one thread finishes the node's whole subtree.  The steps of a split, in every class:
 //   1. centroid range per axis (f32 min/max are exact and order-independent; for the multi-workgroup path it is a by-product of
 //      the parent's scatter pass, the root's of make_proxies)
 //   2. "first plane the centroid is below" binning with the reference's own plane values and `<` comparisons
@@ -40,11 +40,12 @@ constexpr uint32_t kSubFlag = 0x80000000u;   // BNode::left = kSubFlag | pool in
 constexpr uint32_t kBig = 2048;            // nodes with more triangles are split by many workgroups (chunks of kChunk).  = kWaveMax: round 3 had a one-workgroup-per-node
                                            // class in between (2 049..8 192, eight passes behind barriers); once big_scatter lost its scratch traffic the chunked path beat it
 constexpr uint32_t kChunk = 8192;
-constexpr uint32_t kSub = 8;               // nodes this small: ONE thread finishes the whole subtree (build_subtree_tiny)
-constexpr uint32_t kTiny = 16;              // nodes this small are built by ONE thread running the reference's loops as written
+constexpr uint32_t kSub = 4;               // nodes this small: ONE thread finishes the whole subtree (build_subtree_tiny).  (kSub, kTiny) swept in round 4:
+                                           // (8,16) 18.2 ms, (4,8) 16.9, (4,12) 16.9, (5,10) 17.0, (2,8) 18.1, (12,16) 21.7, (16,16) 29 -- profiles/r4_bvh_sub_tiny_sweep.txt
+constexpr uint32_t kTiny = 8;               // nodes this small (and larger than kSub) are split by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
-constexpr uint32_t kWaveMax = 2048;          // 17..kWaveMax triangles: one wave64 per node (build_level_wave)
-enum { CLS_WAVE = 0, CLS_TINY = 1, CLS_BIG = 2, CLS_SUB = 3, CLS_WAVE_M = 4, CLS_WAVE_L = 5, kClasses = 6 };   // CLS_WAVE: 17..64, _M: 65..512, _L: 513..kWaveMax triangles
+constexpr uint32_t kWaveMax = 2048;          // kTiny+1..kWaveMax triangles: one wave64 per node (build_level_wave)
+enum { CLS_WAVE = 0, CLS_TINY = 1, CLS_BIG = 2, CLS_SUB = 3, CLS_WAVE_M = 4, CLS_WAVE_L = 5, kClasses = 6 };   // CLS_WAVE: kTiny+1..64, _M: 65..512, _L: 513..kWaveMax triangles
 constexpr uint32_t kWaveS = 64u, kWaveM = 512u;
 // per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
 // children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
@@ -188,7 +189,7 @@ __global__ void init_root(BNode *bn, const uint32_t *rootkeys, uint32_t n) {
     bn[0] = r;
 }
 
-// ---- nodes with 17..kWaveMax triangles: one wave64 per node, four nodes per workgroup; the same five steps with wave-level
+// ---- nodes with kTiny+1..kWaveMax triangles: one wave64 per node, four nodes per workgroup; the same five steps with wave-level
 // reductions (f32 min/max and integer sums are exact in any order), a wave-private LDS region and no block barrier ----------
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // Wave-wide reductions of a value every lane holds (all 64 lanes active), result uniform.  Four DPP stages (lane ^ 1, lane ^ 2 inside a
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(64) void build_level_tiny(BNode *bn, const uint32_t
 // ---- nodes with <= kSub triangles: one thread builds the node's WHOLE subtree (round 3) --------------------------------
 // The level-synchronous scheme spent most of its time here: one launch, one host read-back and one pass over global memory per
 // tree level for nodes that hold a handful of triangles (31 levels at 10 M triangles, the last ~12 of them nothing but such nodes).
-// Now the thread that reaches a node with <= 16 triangles loads its proxies into LDS ([slot][word][thread]: conflict-free) and
+// Now the thread that reaches a node with <= kSub triangles loads its proxies into LDS ([slot][word][thread]: conflict-free) and
 // runs the reference's recursion to the end -- split_node (bvh.rs:56-136) with evaluate_sah (:138-161) as written, the partition
 // loop (:99-108) in place, children pushed in pairs and then left before right (:131-135) -- with an explicit stack.  The
 // subtree's nodes go to a pool in exactly the order the reference appends them, so their final indices are base(X) + local index
