@@ -1021,6 +1021,32 @@ __global__ void bases_level(BNode *bn, uint32_t begin, uint32_t end) {          
         bn[l].base = b + 2u; bn[l + 1].base = b + 2u + bn[l].size;
     }
 }
+// The same two passes for a RUN of consecutive small levels in one launch (one workgroup, a barrier between levels): the top of the tree
+// and its last few levels hold a handful of nodes each, and a launch per level and pass was 58 launches ~ 0.9 ms of a 17-ms build.
+constexpr uint32_t kRunLevels = 32, kRunNodes = 4096;        // a run: up to 32 levels of at most 4 096 nodes each (wider levels pay more in one workgroup than a launch costs)
+struct LevelRun { uint32_t b[kRunLevels + 1]; uint32_t n; };  // level i of the run = nodes [b[i], b[i + 1])
+__global__ __launch_bounds__(1024) void sizes_run(BNode *bn, LevelRun r) {                // bottom-up
+    for (int i = (int)r.n - 1; i >= 0; i--) {
+        for (uint32_t j = r.b[i] + threadIdx.x; j < r.b[i + 1]; j += blockDim.x) {
+            const uint32_t l = bn[j].left;
+            if (l != kNone && (l & kSubFlag)) continue;
+            bn[j].size = (l == kNone) ? 0u : 2u + bn[l].size + bn[l + 1].size;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void bases_run(BNode *bn, LevelRun r) {                // top-down
+    for (uint32_t i = 0; i < r.n; i++) {
+        for (uint32_t j = r.b[i] + threadIdx.x; j < r.b[i + 1]; j += blockDim.x) {
+            const uint32_t l = bn[j].left;
+            if (l == kNone || (l & kSubFlag)) continue;
+            const uint32_t b = bn[j].base;
+            bn[l].dfs = b; bn[l + 1].dfs = b + 1u;
+            bn[l].base = b + 2u; bn[l + 1].base = b + 2u + bn[l].size;
+        }
+        __syncthreads();
+    }
+}
 __global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, const PoolNode *__restrict__ pool, MiptNode *nodes) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x) {
         const BNode b = bn[i];
@@ -1190,13 +1216,39 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     const uint32_t n_nodes = n_bn + hc.sub_nodes.v;
     lvl_begin.push_back(n_bn);
     if (n_nodes > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-    for (int l = (int)lvl_begin.size() - 2; l >= 0; l--) {
-        const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
-        hipLaunchKernelGGL(sizes_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
-    }
-    for (size_t l = 0; l + 1 < lvl_begin.size(); l++) {
-        const uint32_t b = lvl_begin[l], e = lvl_begin[l + 1];
-        hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+    {   // subtree sizes bottom-up, then depth-first bases top-down: runs of small levels in one launch each, wide levels one by one
+        const int n_lvl = (int)lvl_begin.size() - 1;
+        auto small = [&](int l) { return lvl_begin[(size_t)l + 1] - lvl_begin[(size_t)l] <= kRunNodes; };
+        for (int l = n_lvl - 1; l >= 0;) {
+            if (!small(l)) {
+                const uint32_t b = lvl_begin[(size_t)l], e = lvl_begin[(size_t)l + 1];
+                hipLaunchKernelGGL(sizes_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+                l--;
+                continue;
+            }
+            int lo = l;
+            while (lo - 1 >= 0 && small(lo - 1) && l - (lo - 1) + 1 <= (int)kRunLevels) lo--;
+            LevelRun r;
+            r.n = (uint32_t)(l - lo + 1);
+            for (int i = 0; i <= l - lo + 1; i++) r.b[i] = lvl_begin[(size_t)(lo + i)];
+            hipLaunchKernelGGL(sizes_run, dim3(1), dim3(1024), 0, nullptr, d_bn, r);
+            l = lo - 1;
+        }
+        for (int l = 0; l < n_lvl;) {
+            if (!small(l)) {
+                const uint32_t b = lvl_begin[(size_t)l], e = lvl_begin[(size_t)l + 1];
+                hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+                l++;
+                continue;
+            }
+            int hi = l;
+            while (hi + 1 < n_lvl && small(hi + 1) && (hi + 1) - l + 1 <= (int)kRunLevels) hi++;
+            LevelRun r;
+            r.n = (uint32_t)(hi - l + 1);
+            for (int i = 0; i <= hi - l + 1; i++) r.b[i] = lvl_begin[(size_t)(l + i)];
+            hipLaunchKernelGGL(bases_run, dim3(1), dim3(1024), 0, nullptr, d_bn, r);
+            l = hi + 1;
+        }
     }
     hipLaunchKernelGGL(emit_nodes, dim3(2048), dim3(256), 0, nullptr, d_bn, n_bn, d_pool, d_nodes);
     hipLaunchKernelGGL(extract_order, dim3(2048), dim3(256), 0, nullptr, d_px[cur], n_tris, d_order);
