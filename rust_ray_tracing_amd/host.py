@@ -50,6 +50,9 @@ class RendererOptions:  # renderer.rs:96-116
     is_realtime: bool = False
     # MI355X-path extensions (MiptOptions)
     seed_mode: int = L.SEED_PIXEL_STREAM
+    # the CPU backend's own un-culled traversal (ray.rs:69-81): the reference by construction, and what the parity tests compare
+    # counter for counter with the oracle.  Production use: TRAVERSAL_CULLED with CULL_MARGIN_SAFE -- same frame, 1.7x faster
+    # (the C++ mirror include/mipt_host.hpp and the Rust binding default to it).
     traversal: int = L.TRAVERSAL_REFERENCE
     cull_margin: float = L.CULL_MARGIN_SAFE
     shading: int = L.SHADING_CPU          # SHADING_WGPU: the wgpu shader's material model (rt_compute.wgsl)
