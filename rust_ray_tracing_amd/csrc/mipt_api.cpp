@@ -139,7 +139,7 @@ template <class F> void parallel_for(size_t n, F body) {                 // body
 } // namespace
 
 // ---- pieces shared with the device-resident setup (scene_device.hip) ----
-int mipt::build_material_tables(const MiptSceneDesc *desc, MaterialTables *out) {
+int mipt::build_material_tables(const MiptSceneDesc *desc, MaterialTables *out, bool gather_texels) {
     struct TexDesc { uint32_t offset, width, height; };
     if (!desc->materials || desc->n_materials == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no materials");
     if (desc->n_textures && !desc->textures) return fail(MIPT_ERR_INVALID_ARG, "n_textures > 0 but textures == NULL");
@@ -180,18 +180,26 @@ int mipt::build_material_tables(const MiptSceneDesc *desc, MaterialTables *out) 
         }
         out->mats_full[i] = f;
     }
-    out->texels.resize((size_t)n_texels);
-    for (uint32_t i = 0; i < desc->n_textures; i++)
-        memcpy(out->texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
+    out->n_texels = n_texels;
+    out->tex_offset.resize(desc->n_textures);
+    for (uint32_t i = 0; i < desc->n_textures; i++) out->tex_offset[i] = texs[i].offset;
+    out->texels.clear();
+    if (gather_texels) {
+        out->texels.resize((size_t)n_texels);
+        for (uint32_t i = 0; i < desc->n_textures; i++)
+            memcpy(out->texels.data() + texs[i].offset, desc->textures[i].rgba8, (size_t)texs[i].width * texs[i].height * 4);
+    }
     return MIPT_OK;
 }
 
 int mipt::upload_material_tables(MiptScene *s, const MaterialTables &t) {
     int rc;
-    if ((rc = upload(&s->d_mats, t.mats, 64)) || (rc = upload(&s->d_mats_full, t.mats_full, 128)) || (rc = upload(&s->d_texels, t.texels, 16))) return rc;
+    if ((rc = upload(&s->d_mats, t.mats, 64)) || (rc = upload(&s->d_mats_full, t.mats_full, 128))) return rc;
+    if (!t.texels.empty() || t.n_texels == 0) { if ((rc = upload(&s->d_texels, t.texels, 16))) return rc; }
+    else HIP_TRY(hipMalloc(&s->d_texels, (size_t)t.n_texels * 4));              // filled by the caller (scene_device.hip stages the textures itself)
     s->mats_bytes = t.mats.size() * sizeof(mipt::DevMaterial) < 64 ? 64 : t.mats.size() * sizeof(mipt::DevMaterial);
     s->mats_full_bytes = t.mats_full.size() * sizeof(mipt::DevMaterialFull) < 128 ? 128 : t.mats_full.size() * sizeof(mipt::DevMaterialFull);
-    s->texel_bytes = t.texels.size() * 4 < 16 ? 16 : t.texels.size() * 4;
+    s->texel_bytes = (size_t)t.n_texels * 4 < 16 ? 16 : (size_t)t.n_texels * 4;
     s->dev.mats = (const mipt::DevMaterial *)s->d_mats;
     s->dev.mats_full = (const mipt::DevMaterialFull *)s->d_mats_full;
     s->dev.texels = (const uint32_t *)s->d_texels;

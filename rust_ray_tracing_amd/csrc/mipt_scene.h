@@ -49,10 +49,14 @@ int scene_clone_to(const MiptScene *src, int device, MiptScene **out);
 struct MaterialTables {
     std::vector<DevMaterial> mats;
     std::vector<DevMaterialFull> mats_full;
-    std::vector<uint32_t> texels;
+    std::vector<uint32_t> texels;             // the pool, when build_material_tables was asked to gather it
+    std::vector<uint32_t> tex_offset;         // first texel of texture i in the pool
+    uint64_t n_texels = 0;
 };
-int build_material_tables(const MiptSceneDesc *desc, MaterialTables *out);          // validates the texture references
-int upload_material_tables(MiptScene *s, const MaterialTables &t);                  // on the current device
+// validates the texture references; gather_texels = false leaves `texels` empty (the caller moves the textures into the pool itself)
+int build_material_tables(const MiptSceneDesc *desc, MaterialTables *out, bool gather_texels = true);
+// on the current device.  With an empty `texels` the pool is allocated (n_texels) but not filled.
+int upload_material_tables(MiptScene *s, const MaterialTables &t);
 
 // BVH::build (bvh.rs:13-161) on the GPU with everything staying in HBM (bvh_build_device.hip): `d_tris` in, the node array in the
 // reference's order and the triangle permutation out (reordered[t] = original[d_tri_order[t]]); both hipMalloc'ed, owned by the caller.

@@ -3,9 +3,9 @@
 // What the reference does between loading an OBJ and the first frame is BVH::build on the host (reference src/bvh.rs:13-54, minutes
 // at 10 M triangles) and one upload of the flat arrays (src/renderer/backend/gpu.rs:329-339).  Here the triangle array crosses PCIe
 // ONCE and everything else happens in HBM:
-//   1. staged upload: worker threads copy 16-MB chunks of the caller's (pageable) array into a ring of pinned buffers, the copy
+//   1. staged upload: a crew of copy threads moves chunks of the caller's (pageable) array into a ring of pinned buffers, the copy
 //      engine drains the ring (measured: 22 ms for 1.12 GB against 213 ms for a plain hipMemcpy of untouched pageable memory,
-//      tools/calib/h2d_rate.hip);
+//      tools/calib/h2d_rate.hip); the textures take the same road;
 //   2. BVH::build on the GPU (bvh_build_device.hip, mipt::bvh_build_resident): node array in the reference's order + the triangle
 //      permutation, both left in HBM;
 //   3. the device layout of pt_kernel.h, built by the kernels below from those two arrays -- bit for bit what mipt_scene_create's
@@ -23,6 +23,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -300,49 +301,99 @@ __global__ void write_tris(const MiptTriangle *tris, const uint32_t *tri_order, 
     if (blockIdx.x == 0 && threadIdx.x == 0) tri_pos[(size_t)n_tris * 4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the kernel's unconditional 4th-float4 load of the last record's neighbour
 }
 
-// ---- staged host -> device copy of a large pageable array ----
-int upload_staged(void *d_dst, const void *h_src, size_t bytes) {
-    constexpr size_t kChunk = (size_t)16 << 20;
-    constexpr int kRing = 4, kThreads = 4;
-    if (bytes < 2 * kChunk) {
-        const hipError_t e = hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice);
-        return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("triangle upload: ") + hipGetErrorString(e));
-    }
-    char *pin[kRing] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t s = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    for (int i = 0; i < kRing && e == hipSuccess; i++) {
-        e = hipHostMalloc((void **)&pin[i], kChunk, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-    }
-    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
-    bool spawn_failed = false;
-    for (size_t c = 0; c < n_chunks && e == hipSuccess && !spawn_failed; c++) {
-        const int slot = (int)(c % kRing);
-        if (c >= (size_t)kRing) e = hipEventSynchronize(ev[slot]);            // the copy engine is done with this buffer
-        if (e != hipSuccess) break;
-        const size_t off = c * kChunk, len = off + kChunk <= bytes ? kChunk : bytes - off;
-        const char *src = (const char *)h_src + off;
-        char *dst = pin[slot];
-        {
-            std::vector<std::thread> th;
-            auto part = [=](int t) { const size_t b = len / kThreads * (size_t)t, en = t == kThreads - 1 ? len : len / kThreads * (size_t)(t + 1); memcpy(dst + b, src + b, en - b); };
-            try { for (int t = 1; t < kThreads; t++) th.emplace_back(part, t); }
-            catch (const std::exception &) { spawn_failed = true; }
-            part(0);
-            for (auto &x : th) x.join();
-            if (spawn_failed) memcpy(dst, src, len);                          // no helper threads: the caller copies the whole chunk
-            spawn_failed = false;
+// ---- staged host -> device copies of large pageable arrays ----
+// A crew of copy threads (started once per scene) moves chunk after chunk of the caller's memory into a ring of pinned buffers; the copy
+// engine drains the ring.  8-MB chunks: small enough that pinning the ring is cheap (32 MB: ~8 ms to allocate, ~5 ms to free -- a
+// 64-MB ring cost 26 ms per scene), large enough for full PCIe rate once the threads no longer have to be spawned per chunk.
+class StagedUploader {
+  public:
+    static constexpr size_t kChunk = (size_t)8 << 20;
+    static constexpr int kRing = 4, kThreads = 4;
+    ~StagedUploader() { shut(); }
+    // one copy; small ones go straight through hipMemcpy
+    int copy(void *d_dst, const void *h_src, size_t bytes) {
+        if (bytes == 0) return MIPT_OK;
+        if (bytes < 2 * kChunk && !ready_) return direct(d_dst, h_src, bytes);
+        if (!ready_) { const int rc = init(); if (rc) return rc == 1 ? direct(d_dst, h_src, bytes) : rc; }
+        const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+        hipError_t e = hipSuccess;
+        for (size_t c = 0; c < n_chunks && e == hipSuccess; c++, seq_++) {
+            const int slot = (int)(seq_ % kRing);
+            if (seq_ >= (size_t)kRing) e = hipEventSynchronize(ev_[slot]);     // the copy engine is done with this buffer
+            if (e != hipSuccess) break;
+            const size_t off = c * kChunk, len = off + kChunk <= bytes ? kChunk : bytes - off;
+            crew_copy((const char *)h_src + off, pin_[slot], len);
+            e = hipMemcpyAsync((char *)d_dst + off, pin_[slot], len, hipMemcpyHostToDevice, stream_);
+            if (e == hipSuccess) e = hipEventRecord(ev_[slot], stream_);
         }
-        e = hipMemcpyAsync((char *)d_dst + off, dst, len, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipEventRecord(ev[slot], s);
+        return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("staged upload: ") + hipGetErrorString(e));
     }
-    if (s) { const hipError_t e2 = hipStreamSynchronize(s); if (e == hipSuccess) e = e2; }
-    for (int i = 0; i < kRing; i++) { if (pin[i]) (void)hipHostFree(pin[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
-    if (s) (void)hipStreamDestroy(s);
-    return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("triangle upload: ") + hipGetErrorString(e));
-}
+    int finish() {                                             // everything queued so far has arrived
+        if (!ready_) return MIPT_OK;
+        const hipError_t e = hipStreamSynchronize(stream_);
+        return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("staged upload: ") + hipGetErrorString(e));
+    }
+    void shut() {
+        if (!th_.empty()) { quit_.store(true); gen_.fetch_add(1, std::memory_order_release); for (auto &x : th_) x.join(); th_.clear(); }
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        for (int i = 0; i < kRing; i++) { if (pin_[i]) (void)hipHostFree(pin_[i]); if (ev_[i]) (void)hipEventDestroy(ev_[i]); pin_[i] = nullptr; ev_[i] = nullptr; }
+        if (stream_) (void)hipStreamDestroy(stream_);
+        stream_ = nullptr; ready_ = false;
+    }
+
+  private:
+    int direct(void *d_dst, const void *h_src, size_t bytes) {
+        const hipError_t e = hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice);
+        return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+    }
+    int init() {                                               // 0 ok, 1 = no pinned memory / stream: fall back to hipMemcpy, < 0 error
+        hipError_t e = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+        for (int i = 0; i < kRing && e == hipSuccess; i++) {
+            e = hipHostMalloc((void **)&pin_[i], kChunk, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); shut(); return 1; }
+        try { for (int t = 1; t < kThreads; t++) th_.emplace_back([this, t]() { worker(t); }); }
+        catch (const std::exception &) {}                      // fewer helpers: the shares are computed from the crew's real size
+        n_ = 1 + (int)th_.size();
+        ready_ = true;
+        return 0;
+    }
+    void part(int t) const {
+        const size_t b = len_ / (size_t)n_ * (size_t)t, e = t == n_ - 1 ? len_ : len_ / (size_t)n_ * (size_t)(t + 1);
+        memcpy(dst_ + b, src_ + b, e - b);
+    }
+    void worker(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t g;
+            while ((g = gen_.load(std::memory_order_acquire)) == seen) std::this_thread::yield();
+            if (quit_.load()) return;
+            seen = g;
+            part(t);
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void crew_copy(const char *src, char *dst, size_t len) {
+        src_ = src; dst_ = dst; len_ = len;
+        done_.store(0, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        part(0);
+        while (done_.load(std::memory_order_acquire) < n_ - 1) std::this_thread::yield();
+    }
+    hipStream_t stream_ = nullptr;
+    char *pin_[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::thread> th_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> done_{0};
+    std::atomic<bool> quit_{false};
+    const char *src_ = nullptr;
+    char *dst_ = nullptr;
+    size_t len_ = 0, seq_ = 0;
+    int n_ = 1;
+    bool ready_ = false;
+};
 
 #define S_HIP(expr)                                                                                                    \
     do {                                                                                                               \
@@ -359,7 +410,7 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     if (desc->n_tris > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, std::to_string(desc->n_tris) + " triangles exceed the 2^25 device-format limit");
     const double t_begin = now_ms();
     mipt::MaterialTables tables;
-    { const int rc = mipt::build_material_tables(desc, &tables); if (rc) return rc; }
+    { const int rc = mipt::build_material_tables(desc, &tables, false); if (rc) return rc; }     // the textures are staged below, not gathered on the host
     const uint32_t n_tris = desc->n_tris;
 
     int ndev = 0;
@@ -372,7 +423,9 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     mipt::ResidentBvh bvh;
     char *arena = nullptr;
     MiptScene *s = nullptr;
+    StagedUploader up_ring;
     auto cleanup = [&]() {
+        up_ring.shut();
         if (d_tris) (void)hipFree(d_tris);
         if (bvh.d_nodes) (void)hipFree(bvh.d_nodes);
         if (bvh.d_tri_order) (void)hipFree(bvh.d_tri_order);
@@ -382,7 +435,11 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     S_HIP(hipSetDevice(device_id));
     // ---- 1. the one host -> device copy ----
     S_HIP(hipMalloc((void **)&d_tris, (size_t)n_tris * sizeof(MiptTriangle)));
-    { const int rc = upload_staged(d_tris, desc->tris, (size_t)n_tris * sizeof(MiptTriangle)); if (rc) { cleanup(); return rc; } }
+    {
+        int rc = up_ring.copy(d_tris, desc->tris, (size_t)n_tris * sizeof(MiptTriangle));
+        if (rc == MIPT_OK) rc = up_ring.finish();
+        if (rc) { cleanup(); return rc; }
+    }
     const double t_up = now_ms();
     // ---- 2. BVH::build in HBM ----
     { const int rc = mipt::bvh_build_resident(d_tris, n_tris, device_id, &bvh); if (rc) { cleanup(); return rc; } }
@@ -479,7 +536,14 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     s->d_nodes = bvh.d_nodes; bvh.d_nodes = nullptr;                // kept for mipt_scene_get_bvh
     s->n_nodes = n_nodes;
     s->d_tri_order = bvh.d_tri_order; bvh.d_tri_order = nullptr;
-    { const int rc = mipt::upload_material_tables(s, tables); if (rc) { cleanup(); return rc; } }
+    {   // materials + the texel pool; the textures go through the same pinned ring, straight from the caller's buffers
+        int rc = mipt::upload_material_tables(s, tables);
+        for (uint32_t i = 0; i < desc->n_textures && rc == MIPT_OK; i++)
+            rc = up_ring.copy((uint32_t *)s->d_texels + tables.tex_offset[i], desc->textures[i].rgba8, (size_t)desc->textures[i].width * desc->textures[i].height * 4);
+        if (rc == MIPT_OK) rc = up_ring.finish();
+        up_ring.shut();
+        if (rc) { cleanup(); return rc; }
+    }
     { const int rc = mipt::scene_finish_workspace(s); if (rc) { cleanup(); return rc; } }
     s->dev.pairs = d_pairs;
     s->dev.tri_pos = d_pos;

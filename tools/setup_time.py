@@ -1,6 +1,9 @@
 """GPU box: mipt_scene_create_from_triangles on the 10 M-triangle scene, three times in one process (first call = cold HIP runtime);
 prints MiptSceneInfo of each.  Under `rocprofv3 --hip-trace --stats` the API table shows what the first call's extra time is made of."""
 import os, sys, time
+if os.environ.get("SETUP_TIME_TORCH"):            # like bench.py: torch has initialised the HIP runtime before the first call
+    import torch
+    torch.zeros(1, device="cuda"); torch.cuda.synchronize()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rust_ray_tracing_amd as rrt
 from rust_ray_tracing_amd import synth
