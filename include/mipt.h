@@ -175,7 +175,7 @@ MIPT_API void mipt_scene_destroy(MiptScene *scene);
 /* The same scene from its TRIANGLES alone -- desc->nodes / n_nodes are ignored (may be NULL / 0): BVH::build (bvh.rs:13-161) runs on
  * the GPU and everything after the one host -> device copy of the triangle array stays in HBM: the node array in the reference's
  * order, the re-based pair records, both triangle streams.  The tree, the triangle order and every byte of the device layout are
- * identical to mipt_bvh_build + mipt_scene_create (sign of zero in a bound aside); only the time differs (10 M triangles: ~0.15 s
+ * identical to mipt_bvh_build + mipt_scene_create (sign of zero in a bound aside); only the time differs (10 M triangles: ~0.08 s
  * against ~10 s of host build or 1.3 s of mipt_bvh_build_device + mipt_scene_create).  The triangle array is read in the caller's
  * order and not modified; mipt_scene_get_bvh returns what BVH::build would have left in the host's Scene. */
 MIPT_API int mipt_scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out);
