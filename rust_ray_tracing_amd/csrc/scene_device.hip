@@ -20,6 +20,7 @@
 #include "../../include/mipt.h"
 #include "mipt_internal.h"
 #include "mipt_scene.h"
+#include "copy_crew.h"
 
 #include <hip/hip_runtime.h>
 
@@ -308,7 +309,7 @@ __global__ void write_tris(const MiptTriangle *tris, const uint32_t *tri_order, 
 class StagedUploader {
   public:
     static constexpr size_t kChunk = (size_t)8 << 20;
-    static constexpr int kRing = 4, kThreads = 4;
+    static constexpr int kRing = 4;
     ~StagedUploader() { shut(); }
     // one copy; small ones go straight through hipMemcpy
     int copy(void *d_dst, const void *h_src, size_t bytes) {
@@ -322,7 +323,7 @@ class StagedUploader {
             if (seq_ >= (size_t)kRing) e = hipEventSynchronize(ev_[slot]);     // the copy engine is done with this buffer
             if (e != hipSuccess) break;
             const size_t off = c * kChunk, len = off + kChunk <= bytes ? kChunk : bytes - off;
-            crew_copy((const char *)h_src + off, pin_[slot], len);
+            crew_.copy((const char *)h_src + off, pin_[slot], len);
             e = hipMemcpyAsync((char *)d_dst + off, pin_[slot], len, hipMemcpyHostToDevice, stream_);
             if (e == hipSuccess) e = hipEventRecord(ev_[slot], stream_);
         }
@@ -334,7 +335,7 @@ class StagedUploader {
         return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("staged upload: ") + hipGetErrorString(e));
     }
     void shut() {
-        if (!th_.empty()) { quit_.store(true); gen_.fetch_add(1, std::memory_order_release); for (auto &x : th_) x.join(); th_.clear(); }
+        crew_.stop();
         if (stream_) (void)hipStreamSynchronize(stream_);
         for (int i = 0; i < kRing; i++) { if (pin_[i]) (void)hipHostFree(pin_[i]); if (ev_[i]) (void)hipEventDestroy(ev_[i]); pin_[i] = nullptr; ev_[i] = nullptr; }
         if (stream_) (void)hipStreamDestroy(stream_);
@@ -353,45 +354,15 @@ class StagedUploader {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming);
         }
         if (e != hipSuccess) { (void)hipGetLastError(); shut(); return 1; }
-        try { for (int t = 1; t < kThreads; t++) th_.emplace_back([this, t]() { worker(t); }); }
-        catch (const std::exception &) {}                      // fewer helpers: the shares are computed from the crew's real size
-        n_ = 1 + (int)th_.size();
+        crew_.start();
         ready_ = true;
         return 0;
-    }
-    void part(int t) const {
-        const size_t b = len_ / (size_t)n_ * (size_t)t, e = t == n_ - 1 ? len_ : len_ / (size_t)n_ * (size_t)(t + 1);
-        memcpy(dst_ + b, src_ + b, e - b);
-    }
-    void worker(int t) {
-        uint64_t seen = 0;
-        for (;;) {
-            uint64_t g;
-            while ((g = gen_.load(std::memory_order_acquire)) == seen) std::this_thread::yield();
-            if (quit_.load()) return;
-            seen = g;
-            part(t);
-            done_.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void crew_copy(const char *src, char *dst, size_t len) {
-        src_ = src; dst_ = dst; len_ = len;
-        done_.store(0, std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_release);
-        part(0);
-        while (done_.load(std::memory_order_acquire) < n_ - 1) std::this_thread::yield();
     }
     hipStream_t stream_ = nullptr;
     char *pin_[kRing] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_[kRing] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<std::thread> th_;
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<int> done_{0};
-    std::atomic<bool> quit_{false};
-    const char *src_ = nullptr;
-    char *dst_ = nullptr;
-    size_t len_ = 0, seq_ = 0;
-    int n_ = 1;
+    mipt::CopyCrew crew_{4};
+    size_t seq_ = 0;
     bool ready_ = false;
 };
 

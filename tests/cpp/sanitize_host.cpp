@@ -15,6 +15,7 @@
 static std::string g_err;
 void mipt_internal_set_error(const char *m) { g_err = m ? m : ""; }
 #include "../../rust_ray_tracing_amd/csrc/mipt_internal.h"   // mipt::pair_order / mipt::tri_slots (bvh_build.cpp)
+#include "../../rust_ray_tracing_amd/csrc/copy_crew.h"       // the copy threads of the staged scene upload (scene_device.hip)
 extern "C" void mipt_material_default(MiptMaterial *m) { memset(m, 0, sizeof *m); m->base_color = {0.8f, 0.8f, 0.8f}; m->base_color_tex_id = m->emission_tex_id = UINT32_MAX; }
 namespace mipt_png { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
 namespace mipt_jpeg { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }
@@ -129,6 +130,29 @@ int main(int argc, char **argv) {
             for (uint32_t j = 0; j < cnt; j++)
                 for (uint32_t q = 1; q < nodes[j].num_tris; q++)
                     if (slot[nodes[j].first_tri_or_child + q] != slot[nodes[j].first_tri_or_child] + q) return 12;
+        }
+    }
+    // 4. the copy crew of the staged upload: many posts of odd sizes (incl. 0 and sizes below the crew size), restarted once --
+    // the post / done protocol must be race-free (TSan) and every byte must arrive (ASan: no slice past the end)
+    {
+        std::vector<unsigned char> src(3u << 20), dst(3u << 20);
+        for (size_t i = 0; i < src.size(); i++) src[i] = (unsigned char)(i * 2654435761u >> 13);
+        for (int round = 0; round < 2; round++) {
+            mipt::CopyCrew crew(4);
+            crew.start();
+            size_t off = 0;
+            for (int it = 0; it < 400 && off < src.size(); it++) {
+                size_t len = it % 7 == 0 ? (size_t)(it % 5) : (size_t)(rng() % 20000) + 1;
+                if (off + len > src.size()) len = src.size() - off;
+                crew.copy(src.data() + off, dst.data() + off, len);
+                off += len;
+            }
+            crew.copy(src.data() + off, dst.data() + off, src.size() - off);
+            if (memcmp(src.data(), dst.data(), src.size()) != 0) return 15;
+            memset(dst.data(), 0, dst.size());
+            crew.stop();
+            crew.copy(src.data(), dst.data(), 4096);                      // restarts itself
+            if (memcmp(src.data(), dst.data(), 4096) != 0) return 16;
         }
     }
     printf("big obj: %d loaded / %d rejected\n", obj_ok, obj_bad);
