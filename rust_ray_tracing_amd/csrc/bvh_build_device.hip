@@ -45,12 +45,13 @@ constexpr uint32_t kSub = 4;               // nodes this small: ONE thread finis
 constexpr uint32_t kTiny = 8;               // nodes this small (and larger than kSub) are split by ONE thread running the reference's loops as written
 constexpr uint32_t kCopies = 8;             // private copies of the LDS bin table in the workgroup kernels
 constexpr uint32_t kWaveMax = 2048;          // kTiny+1..kWaveMax triangles: one wave64 per node (build_level_wave)
-enum { CLS_WAVE = 0, CLS_TINY = 1, CLS_BIG = 2, CLS_SUB = 3, CLS_WAVE_M = 4, CLS_WAVE_L = 5, kClasses = 6 };   // CLS_WAVE: kTiny+1..64, _M: 65..512, _L: 513..kWaveMax triangles
+enum { CLS_WAVE = 0, CLS_TINY = 1, CLS_BIG = 2, CLS_SUB = 3, CLS_WAVE_M = 4, CLS_WAVE_L = 5, CLS_G16 = 6, CLS_G32 = 7, CLS_WAVE_A = 8, kClasses = 9 };   // CLS_G16: kTiny+1..16 and CLS_G32: 17..32 (several nodes per wave), CLS_WAVE: 33..64, _A: 65..128, _M: 129..512, _L: 513..kWaveMax triangles
 constexpr uint32_t kWaveS = 64u, kWaveM = 512u;
-// per-level work lists: ctrl->cnt[parity][class] entries in lists[parity][class]; level L reads parity L&1 and appends the
-// children it creates to parity (L+1)&1.  Nodes above kBig are found by the host (top levels only).
+// per-level work lists: lists[parity][class], level L reads parity L & 1 and appends the children it creates to parity (L + 1) & 1.  Their
+// lengths live in THREE rotating counter rows, ctrl->cnt[L % 3][class]: while level L runs, row (L + 2) % 3 -- last read two levels ago --
+// is zeroed on a side stream, so no reset sits between two levels.  Kernels get "next" = list parity | counter row << 8 of the level they feed.
 struct alignas(128) Pad32 { uint32_t v; uint32_t pad[31]; };        // one counter per 128-B line: atomics on one line serialise, whichever word they hit
-struct Ctrl { Pad32 n_nodes, n_chunks, cnt[2][kClasses + 1], pool_alloc, sub_nodes; };   // cnt[parity][kClasses]: centroid-range records handed to that level's big nodes (big_finish); pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
+struct Ctrl { Pad32 n_nodes, n_chunks, cnt[3][kClasses + 1], pool_alloc, sub_nodes; };   // cnt[parity][kClasses]: centroid-range records handed to that level's big nodes (big_finish); pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
 struct Lists { uint32_t *l[2][kClasses]; };
 
 struct alignas(16) Proxy {                                            // 32 B = two 16-B words
@@ -92,14 +93,18 @@ __device__ __forceinline__ float box_area(const float *lo, const float *hi) {   
 __host__ __device__ __forceinline__ uint32_t node_class(uint32_t n) {
     if (n > kBig) return (uint32_t)CLS_BIG;
     if (n > kWaveM) return (uint32_t)CLS_WAVE_L;
-    if (n > kWaveS) return (uint32_t)CLS_WAVE_M;
-    if (n > kTiny) return (uint32_t)CLS_WAVE;
+    if (n > 128u) return (uint32_t)CLS_WAVE_M;
+    if (n > kWaveS) return (uint32_t)CLS_WAVE_A;
+    if (n > 32u) return (uint32_t)CLS_WAVE;
+    if (n > 16u) return (uint32_t)CLS_G32;
+    if (n > kTiny) return (uint32_t)CLS_G16;
     return n > kSub ? (uint32_t)CLS_TINY : (uint32_t)CLS_SUB;
 }
 __device__ __forceinline__ uint32_t mask_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-__device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint32_t parity, uint32_t base_idx, uint32_t na, uint32_t nb) {
+__device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint32_t next, uint32_t base_idx, uint32_t na, uint32_t nb) {
+    const uint32_t parity = next & 1u, row = next >> 8;
     const uint32_t ca = node_class(na), cb = node_class(nb);
     const unsigned long long active = __ballot(true);
     const int leader = (int)__ffsll((long long)active) - 1;
@@ -112,7 +117,7 @@ __device__ __forceinline__ void queue_children(Ctrl *ctrl, const Lists &ls, uint
     for (uint32_t c = 0; c < (uint32_t)kClasses; c++) {               // all the wave's list atomics in flight together: one round trip, not one per class
         const uint32_t tot = (uint32_t)__popcll(ma[c]) + (uint32_t)__popcll(mb[c]);
         slot0[c] = 0;
-        if (tot != 0u && (int)lane == leader) slot0[c] = atomicAdd(&ctrl->cnt[parity][c].v, tot);
+        if (tot != 0u && (int)lane == leader) slot0[c] = atomicAdd(&ctrl->cnt[row][c].v, tot);
     }
 #pragma unroll
     for (uint32_t c = 0; c < (uint32_t)kClasses; c++) {
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(64 * NODES, MINW) void build_level_wave(BNode *bn, 
             const BNode nd = bn[node_i];
             first = nd.first;
             if (kS >= 8 && n <= 4u * 64u) {                          // the smallest instantiation that holds the node
-                if (n <= 128u) r = wave_node<2>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
+                if (LO < 128u && n <= 128u) r = wave_node<2>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
                 else r = wave_node<4>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
             } else if (kS >= 32 && n <= 16u * 64u) {
                 r = wave_node<16>(nd, pin, pout, lane, s_keyw[wv], s_cntw[wv], s_hp[wv], s_tp[wv]);
@@ -454,6 +459,176 @@ __global__ __launch_bounds__(64 * NODES, MINW) void build_level_wave(BNode *bn, 
     __syncthreads();
     if (wv == 0u) {                                                  // lanes 0..NODES-1 each emit one node's children
         const bool mine = lane < (uint32_t)NODES && s_k[lane] != 0u;
+        if (mine) emit_children(bn, ctrl, ls, next_parity, s_node[lane], s_box[lane][0], s_box[lane][1], s_first[lane], s_k[lane], s_n[lane]);
+    }
+}
+
+// ---- small wave-class nodes, SEVERAL PER WAVE: a node with <= G triangles (G = 16, 32) occupies an aligned group of G lanes, one
+// proxy per lane -- the same five steps as wave_node<1> with the reductions, ballots and rank computations confined to the group.
+// Most nodes of the deep levels hold 9..32 triangles; a whole wave each left three quarters of the lanes idle through a chain of
+// ~20 dependent reductions.  Everything here is executed by all 64 lanes (the DPP reductions need them); a group without a node, or
+// whose node stays a leaf, carries neutral values through the later steps.
+template <int G, class Op> __device__ __forceinline__ uint32_t group_reduce_bits(uint32_t v, Op op) {
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));               // quad_perm [1,0,3,2]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));               // quad_perm [2,3,0,1]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));              // row_half_mirror: 8 lanes
+    if (G >= 16) v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false)); // row_mirror: a row of 16
+    if (G >= 32) v = op(v, (uint32_t)__shfl_xor((int)v, 16));                                          // the neighbouring row
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_fmin(float v) {
+    return __uint_as_float(group_reduce_bits<G>(__float_as_uint(v), [](uint32_t a, uint32_t b) { return __float_as_uint(fminf(__uint_as_float(a), __uint_as_float(b))); }));
+}
+template <int G> __device__ __forceinline__ float group_fmax(float v) {
+    return __uint_as_float(group_reduce_bits<G>(__float_as_uint(v), [](uint32_t a, uint32_t b) { return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b))); }));
+}
+template <int G> __device__ __forceinline__ uint32_t group_umin(uint32_t v) { return group_reduce_bits<G>(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+template <int G> __device__ __forceinline__ uint32_t group_sum(uint32_t v) { return group_reduce_bits<G>(v, [](uint32_t a, uint32_t b) { return a + b; }); }
+
+template <int G, uint32_t LO, uint32_t HI>
+__global__ __launch_bounds__(512, (G == 16 ? 6 : 8)) void build_level_group(BNode *bn, const uint32_t *__restrict__ list, uint32_t count, const Proxy *__restrict__ pin,
+                                                            Proxy *__restrict__ pout, Ctrl *ctrl, Lists ls, uint32_t next_parity) {
+    static_assert(G == 16 || G == 32, "group of 16 or 32 lanes");
+    constexpr int kPerWave = 64 / G, kWaves = 8, kNodes = kPerWave * kWaves;     // nodes per workgroup: 32 (G = 16) or 16 (G = 32)
+    __shared__ uint32_t s_key[kNodes][3][8][6];
+    __shared__ uint32_t s_cnt[kNodes][3][8];
+    __shared__ uint32_t s_hp[kNodes][G], s_tp[kNodes][G];
+    __shared__ uint32_t s_node[kNodes], s_first[kNodes], s_n[kNodes], s_k[kNodes];
+    __shared__ Box3 s_box[kNodes][2];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lig = lane & (uint32_t)(G - 1), grp = lane / (uint32_t)G;            // lane in group, group in wave
+    const uint32_t slot = wv * (uint32_t)kPerWave + grp;                                 // the group's node slot in the workgroup
+    const uint32_t item = blockIdx.x * (uint32_t)kNodes + slot;
+    const uint32_t gshift = grp * (uint32_t)G;
+    const unsigned long long gmask = (G == 32 ? 0xffffffffull : 0xffffull);
+    uint32_t (*key)[8][6] = s_key[slot];
+    uint32_t (*cnt)[8] = s_cnt[slot];
+    uint32_t *hp = s_hp[slot], *tp = s_tp[slot];
+
+    uint32_t node_i = 0, first = 0, n = 0;
+    float blo0 = 0, blo1 = 0, blo2 = 0, bhi0 = 0, bhi1 = 0, bhi2 = 0;                   // the node's own box
+    bool has = false;
+    if (item < count) {
+        node_i = list[item];
+        const BNode nd = bn[node_i];
+        if (nd.n > LO && nd.n <= HI) {
+            has = true; first = nd.first; n = nd.n;
+            blo0 = nd.lo[0]; blo1 = nd.lo[1]; blo2 = nd.lo[2]; bhi0 = nd.hi[0]; bhi1 = nd.hi[1]; bhi2 = nd.hi[2];
+        }
+    }
+    const Proxy *in = pin + first;
+    Proxy *out = pout + first;
+    const bool valid = has && lig < n;
+    float l0 = F32_MAX, l1 = F32_MAX, l2 = F32_MAX, h0 = -F32_MAX, h1 = -F32_MAX, h2 = -F32_MAX;
+    uint32_t id = 0;
+    if (valid) { const Proxy e = in[lig]; l0 = e.lo[0]; l1 = e.lo[1]; l2 = e.lo[2]; h0 = e.hi[0]; h1 = e.hi[1]; h2 = e.hi[2]; id = e.idx; }
+    const float c0 = (l0 + h0) / 2.0f, c1 = (l1 + h1) / 2.0f, c2 = (l2 + h2) / 2.0f;    // scene.rs:125 (lanes without a proxy: never used)
+    // ---- 1. centroid ranges + planes (bvh.rs:67-84) ----
+    float cmin[3], cmax[3];
+    cmin[0] = group_fmin<G>(valid ? c0 : F32_MAX); cmax[0] = group_fmax<G>(valid ? c0 : -F32_MAX);
+    cmin[1] = group_fmin<G>(valid ? c1 : F32_MAX); cmax[1] = group_fmax<G>(valid ? c1 : -F32_MAX);
+    cmin[2] = group_fmin<G>(valid ? c2 : F32_MAX); cmax[2] = group_fmax<G>(valid ? c2 : -F32_MAX);
+    bool use[3];
+    float scale[3];
+    for (int a = 0; a < 3; a++) { use[a] = !(cmin[a] == cmax[a]); scale[a] = (cmax[a] - cmin[a]) / 8.0f; }
+    for (uint32_t i = lig; i < 144u; i += (uint32_t)G) (&key[0][0][0])[i] = ((i % 6u) < 3u) ? 0xffffffffu : 0u;
+    for (uint32_t i = lig; i < 24u; i += (uint32_t)G) (&cnt[0][0])[i] = 0u;
+    wave_sync();
+    // ---- 2. binning ----
+    if (valid) {
+        const float cc[3] = {c0, c1, c2};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (!use[a]) continue;
+            int k = 8;
+            for (int q = 7; q >= 1; q--) if (cc[a] < cmin[a] + (float)q * scale[a]) k = q;          // first plane the centroid is below
+            uint32_t *kk = key[a][k - 1];
+            lds_min(&kk[0], fkey(l0)); lds_min(&kk[1], fkey(l1)); lds_min(&kk[2], fkey(l2));
+            lds_max(&kk[3], fkey(h0)); lds_max(&kk[4], fkey(h1)); lds_max(&kk[5], fkey(h2));
+            atomicAdd(&cnt[a][k - 1], 1u);
+        }
+    }
+    wave_sync();
+    // ---- 3. SAH: candidate c = 7 * axis + plane - 1 (axis-major / plane-minor); lane `lig` evaluates c = lig, lig + G, ...; the first
+    //         strictly lower cost wins (bvh.rs:86) = the lowest candidate index holding the minimum ----
+    float my_cost = F32_MAX, my_pos = 0.0f;
+    uint32_t my_k = 0, my_c = 0xffu;
+    for (uint32_t c = lig; c < 21u; c += (uint32_t)G) {
+        const int a = (int)(c / 7u), i = (int)(c % 7u) + 1;
+        if (!has || !use[a]) continue;
+        float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+        float rlo[3] = {F32_MAX, F32_MAX, F32_MAX}, rhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+        uint32_t lc = 0, rc = 0;
+        for (int b = 0; b < 8; b++) {                            // an empty bin's untouched keys decode to NaN, which fminf/fmaxf ignore
+            if (b < i) { for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(key[a][b][q])); lhi[q] = fmaxf(lhi[q], funkey(key[a][b][3 + q])); } lc += cnt[a][b]; }
+            else { for (int q = 0; q < 3; q++) { rlo[q] = fminf(rlo[q], funkey(key[a][b][q])); rhi[q] = fmaxf(rhi[q], funkey(key[a][b][3 + q])); } rc += cnt[a][b]; }
+        }
+        const float cost = (float)lc * box_area(llo, lhi) + (float)rc * box_area(rlo, rhi);
+        const float sc = (cost > 0.0f) ? cost : F32_MAX;
+        if (sc < my_cost) { my_cost = sc; my_pos = cmin[a] + (float)i * scale[a]; my_k = lc; my_c = c; }   // (a lane's candidates come in increasing order)
+    }
+    const float best_cost = group_fmin<G>(my_cost);
+    int axis = 0;
+    float pos = 0.0f;
+    uint32_t k = 0;
+    bool k_known = false;
+    {
+        const uint32_t win_c = group_umin<G>((my_cost == best_cost && my_c != 0xffu) ? my_c : 0xffu);
+        if (best_cost < F32_MAX && win_c != 0xffu) {              // else: nothing beat the initial f32::MAX -> axis 0, pos 0.0 (bvh.rs:60-62)
+            const int src = (int)(gshift + (win_c % (uint32_t)G));
+            axis = (int)(win_c / 7u);
+            pos = __shfl(my_pos, src);
+            k = __shfl(my_k, src);
+            k_known = true;
+        }                                                         // (group-uniform branch: the source lanes of the shuffles sit in the same group)
+    }
+    const float nb_lo[3] = {blo0, blo1, blo2}, nb_hi[3] = {bhi0, bhi1, bhi2};
+    const float parent_cost = (float)n * box_area(nb_lo, nb_hi);
+    const bool split_try = has && !(best_cost >= parent_cost);   // bvh.rs:94
+    // ---- 4. the partition permutation (closed form of bvh.rs:99-108) ----
+    const float cax = axis == 0 ? c0 : (axis == 1 ? c1 : c2);
+    const bool less = valid && (cax < pos);
+    {
+        const uint32_t kc = group_sum<G>(less ? 1u : 0u);          // NaN parent cost with no finite candidate: count directly
+        if (!k_known) k = kc;
+    }
+    const bool is_hole = split_try && valid && lig < k && !less;
+    const bool is_tail = split_try && valid && lig >= k && less;
+    const uint32_t mh = (uint32_t)((__ballot(is_hole) >> gshift) & gmask), mt = (uint32_t)((__ballot(is_tail) >> gshift) & gmask);
+    const uint32_t below = (lig == 0u) ? 0u : (0xffffffffu >> (32u - lig));            // bits of the lanes below this one in its group
+    const uint32_t hole_rank = (uint32_t)__popc(mh & below);                             // holes in increasing position
+    const uint32_t tail_rank = (uint32_t)__popc(mt & ~below & ~(1u << lig));             // tails in decreasing position
+    const uint32_t n_holes = (uint32_t)__popc(mh);
+    if (is_hole) hp[hole_rank] = lig;
+    if (is_tail) tp[tail_rank] = lig;
+    wave_sync();
+    const uint32_t t_last = n_holes ? tp[n_holes - 1u] : n;
+    if (valid) {
+        uint32_t dest = lig;                                       // a leaf carries its range over unchanged
+        if (split_try) {
+            if (lig < k) { if (!less) dest = (hole_rank ? tp[hole_rank - 1u] : n) - 1u; }
+            else if (less) dest = hp[tail_rank];
+            else if (lig > t_last) dest = lig - 1u;
+            else dest = (lig == k) ? (t_last - 1u) : (lig - 1u);
+        }
+        Proxy e; e.pad = 0u; e.lo[0] = l0; e.lo[1] = l1; e.lo[2] = l2; e.hi[0] = h0; e.hi[1] = h1; e.hi[2] = h2; e.idx = id;
+        out[dest] = e;
+    }
+    // ---- child boxes (bvh.rs:115-130) ----
+    const bool inA = valid && less, inB = valid && !less;
+    Box3 A, B;
+    A.lx = group_fmin<G>(inA ? l0 : F32_MAX); A.ly = group_fmin<G>(inA ? l1 : F32_MAX); A.lz = group_fmin<G>(inA ? l2 : F32_MAX);
+    A.hx = group_fmax<G>(inA ? h0 : -F32_MAX); A.hy = group_fmax<G>(inA ? h1 : -F32_MAX); A.hz = group_fmax<G>(inA ? h2 : -F32_MAX);
+    B.lx = group_fmin<G>(inB ? l0 : F32_MAX); B.ly = group_fmin<G>(inB ? l1 : F32_MAX); B.lz = group_fmin<G>(inB ? l2 : F32_MAX);
+    B.hx = group_fmax<G>(inB ? h0 : -F32_MAX); B.hy = group_fmax<G>(inB ? h1 : -F32_MAX); B.hz = group_fmax<G>(inB ? h2 : -F32_MAX);
+    const bool split = split_try && k != 0u && k != n;            // bvh.rs:110-113 (cannot fail with a finite best cost)
+    if (lig == 0u) {
+        s_node[slot] = node_i; s_first[slot] = first; s_n[slot] = n; s_k[slot] = split ? k : 0u;     // k == 0 marks "no split" / no node
+        s_box[slot][0] = A; s_box[slot][1] = B;
+    }
+    __syncthreads();
+    if (wv == 0u) {                                                // lanes 0..kNodes-1 each emit one node's children
+        const bool mine = lane < (uint32_t)kNodes && s_k[lane] != 0u;
         if (mine) emit_children(bn, ctrl, ls, next_parity, s_node[lane], s_box[lane][0], s_box[lane][1], s_first[lane], s_k[lane], s_n[lane]);
     }
 }
@@ -998,7 +1173,7 @@ __global__ void big_finish(const BigState *bs, BNode *bn, Ctrl *ctrl, Lists ls, 
     const uint32_t cn[2] = {s.k, s.n - s.k};
     for (uint32_t sd = 0; sd < 2u; sd++) {                              // a child that is big itself starts its level with the range known
         if (cn[sd] <= kBig) continue;
-        const uint32_t slot = atomicAdd(&ctrl->cnt[next_parity][kClasses].v, 1u);
+        const uint32_t slot = atomicAdd(&ctrl->cnt[next_parity >> 8][kClasses].v, 1u);
         if (slot >= crange_cap) continue;                               // cannot happen: a level holds at most n / kBig big nodes (the host checks the counter all the same)
         for (int q = 0; q < 6; q++) crange[(size_t)slot * 6u + (uint32_t)q] = s.ccen[sd][q];
         bn[base + sd].dfs = slot + 1u;
@@ -1107,11 +1282,11 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     ChunkBins *d_cbins = nullptr;
     const uint32_t big_cap = n_tris / kBig + 2u, chunk_cap = n_tris / kChunk + big_cap + 2u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    // The per-level kernels touch disjoint nodes: the chunked path, the three wave kernels and the two thread kernels overlap on three
-    // streams (six measured the same, 16.9 vs 17.1 ms, and cost three more stream creations -- ~6 ms each the first time in a process)
-    hipStream_t sw = nullptr, sg = nullptr, ss = nullptr;
+    // The per-level kernels touch disjoint nodes and overlap on four streams: the chunked path; the 65..512 wave kernel (the longest of
+    // a deep level); the other wave and group kernels; the two thread kernels.  (A stream costs ~6 ms to create the first time in a process.)
+    hipStream_t sw = nullptr, sw2 = nullptr, sg = nullptr, ss = nullptr;
     auto cleanup = [&]() {
-        hipStream_t all[] = {sw, sg, ss};
+        hipStream_t all[] = {sw, sw2, sg, ss};
         for (hipStream_t x : all) if (x) (void)hipStreamDestroy(x);
         void *p[] = {d_px[0], d_px[1], d_bn, d_nodes, d_order, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_cbins, d_crange, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
@@ -1153,9 +1328,10 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipStreamCreate(&sw));                          // blocking streams: ordered against the null stream's copies / launches
+    HIP_TRY(hipStreamCreate(&sw2));
     HIP_TRY(hipStreamCreate(&sg));
     HIP_TRY(hipStreamCreate(&ss));
-    hipStream_t const sw2 = sw, sw3 = sw, st = ss;
+    hipStream_t const sw3 = sw2, st = ss;
     const uint32_t root_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 48, hipMemcpyHostToDevice));
     Ctrl hc;
@@ -1174,16 +1350,19 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     std::vector<uint32_t> lvl_begin;
     uint32_t begin = 0, end = 1;
     int cur = 0;
-    uint32_t parity = 0;
+    uint32_t parity = 0, row = 0;                       // list parity = level & 1, counter row = level % 3
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
-        const uint32_t nb = hc.cnt[parity][CLS_BIG].v;
+        const uint32_t next = (parity ^ 1u) | (((row + 1u) % 3u) << 8);
+        // the counter row of level + 2 was last read two levels ago: zero it now, beside this level's kernels
+        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[(row + 2u) % 3u][0], 0, (kClasses + 1) * sizeof(Pad32), ss));
+        const uint32_t nb = hc.cnt[row][CLS_BIG].v;
         if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk);
                                                         // its own stream: these 9 launches overlap the level's block / wave / tiny kernels
             const uint32_t nc = n_tris / kChunk + nb;   // bound on sum(ceil(n_j / kChunk)); the real count lives in ctrl->n_chunks
             if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             const dim3 gb((nb + 63) / 64), tb(64);
-            if (hc.cnt[parity][kClasses].v > big_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
+            if (hc.cnt[row][kClasses].v > big_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl, d_root, d_crange + (size_t)parity * big_cap * 6);
             hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_cbins, d_px[cur], d_ctrl);
             hipLaunchKernelGGL(big_choose, gb, tb, 0, sg, d_big, nb);
@@ -1192,24 +1371,26 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
             hipLaunchKernelGGL(big_scan, dim3(nb), dim3(64), 0, sg, d_big, d_chunks, d_cbeg, nb);
             hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_hp, d_tp, d_ctrl);
             hipLaunchKernelGGL(big_scatter, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_px[cur ^ 1], d_hp, d_tp, d_ctrl);
-            hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, parity ^ 1u, nb, d_crange + (size_t)(parity ^ 1u) * big_cap * 6, big_cap);
+            hipLaunchKernelGGL(big_finish, gb, tb, 0, sg, d_big, d_bn, d_ctrl, ls, next, nb, d_crange + (size_t)(parity ^ 1u) * big_cap * 6, big_cap);
         }
-        const uint32_t ntin = hc.cnt[parity][CLS_TINY].v, nsub = hc.cnt[parity][CLS_SUB].v;
-        const uint32_t nws = hc.cnt[parity][CLS_WAVE].v, nwm = hc.cnt[parity][CLS_WAVE_M].v, nwl = hc.cnt[parity][CLS_WAVE_L].v;
+        const uint32_t ntin = hc.cnt[row][CLS_TINY].v, nsub = hc.cnt[row][CLS_SUB].v;
+        const uint32_t nws = hc.cnt[row][CLS_WAVE].v, nwm = hc.cnt[row][CLS_WAVE_M].v, nwl = hc.cnt[row][CLS_WAVE_L].v;
+        const uint32_t ng16 = hc.cnt[row][CLS_G16].v, ng32 = hc.cnt[row][CLS_G32].v, nwa = hc.cnt[row][CLS_WAVE_A].v;
         if (nwl) hipLaunchKernelGGL((build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>), dim3((nwl + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes), dim3(64 * kWaveBigNodes), 0, sw3,
-                                    d_bn, ls.l[parity][CLS_WAVE_L], nwl, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-        if (nwm) hipLaunchKernelGGL((build_level_wave<kWaveS, kWaveM, 8, 4>), dim3((nwm + 7u) / 8u), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE_M], nwm, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-        if (nws) hipLaunchKernelGGL((build_level_wave<0u, kWaveS, 8, 8>), dim3((nws + 7u) / 8u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nws, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
-        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 63u) / 64u), dim3(64), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, parity ^ 1u);
+                                    d_bn, ls.l[parity][CLS_WAVE_L], nwl, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (nwm) hipLaunchKernelGGL((build_level_wave<128u, kWaveM, 8, 4>), dim3((nwm + 7u) / 8u), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE_M], nwm, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (nwa) hipLaunchKernelGGL((build_level_wave<kWaveS, 128u, 8, 6>), dim3((nwa + 7u) / 8u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE_A], nwa, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (nws) hipLaunchKernelGGL((build_level_wave<32u, kWaveS, 8, 8>), dim3((nws + 7u) / 8u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nws, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (ng32) hipLaunchKernelGGL((build_level_group<32, 16u, 32u>), dim3((ng32 + 15u) / 16u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_G32], ng32, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (ng16) hipLaunchKernelGGL((build_level_group<16, kTiny, 16u>), dim3((ng16 + 31u) / 32u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_G16], ng16, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 63u) / 64u), dim3(64), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
         if (nsub) hipLaunchKernelGGL(build_subtree_tiny, dim3((nsub + 63u) / 64u), dim3(64), 0, ss, d_bn, ls.l[parity][CLS_SUB], nsub, d_px[cur], d_px[0], d_px[1], d_pool, d_ctrl);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(h_ctrl, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));        // pinned target; also the level's barrier
         hc = *h_ctrl;
         const uint32_t total = hc.n_nodes.v;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        for (int c = 0; c <= kClasses; c++) hc.cnt[parity][c].v = 0u;   // this level's lists (and its centroid-range records) are consumed: reset for level + 2
-        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[parity][0], 0, (kClasses + 1) * sizeof(Pad32), nullptr));     // stream-ordered, no host round trip
-        begin = end; end = total; cur ^= 1; parity ^= 1u;
+        begin = end; end = total; cur ^= 1; parity ^= 1u; row = (row + 1u) % 3u;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
     const uint32_t n_bn = end;                                  // nodes built level by level; the finished subtrees' nodes live in the pool
