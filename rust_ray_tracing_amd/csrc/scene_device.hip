@@ -334,6 +334,7 @@ class StagedUploader {
         const hipError_t e = hipStreamSynchronize(stream_);
         return e == hipSuccess ? MIPT_OK : fail(MIPT_ERR_HIP, std::string("staged upload: ") + hipGetErrorString(e));
     }
+    void pause() { crew_.stop(); }                            // the ring stays; the helpers stop spinning until the next copy
     void shut() {
         crew_.stop();
         if (stream_) (void)hipStreamSynchronize(stream_);
@@ -409,6 +410,7 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     {
         int rc = up_ring.copy(d_tris, desc->tris, (size_t)n_tris * sizeof(MiptTriangle));
         if (rc == MIPT_OK) rc = up_ring.finish();
+        up_ring.pause();                                      // back for the textures, after the build
         if (rc) { cleanup(); return rc; }
     }
     const double t_up = now_ms();
@@ -533,7 +535,6 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     s->info.build_ms = bvh.build_ms;
     s->info.layout_ms = t_layout - t_build;
     s->info.total_ms = t_end - t_begin;
-    (void)t_build;
     *out = s;
     s = nullptr;
     return MIPT_OK;
