@@ -23,7 +23,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -48,11 +50,37 @@ constexpr uint32_t kWaveMax = 2048;          // kTiny+1..kWaveMax triangles: one
 enum { CLS_WAVE = 0, CLS_TINY = 1, CLS_BIG = 2, CLS_SUB = 3, CLS_WAVE_M = 4, CLS_WAVE_L = 5, CLS_G16 = 6, CLS_G32 = 7, CLS_WAVE_A = 8, kClasses = 9 };   // CLS_G16: kTiny+1..16 and CLS_G32: 17..32 (several nodes per wave), CLS_WAVE: 33..64, _A: 65..128, _M: 129..512, _L: 513..kWaveMax triangles
 constexpr uint32_t kWaveS = 64u, kWaveM = 512u;
 // per-level work lists: lists[parity][class], level L reads parity L & 1 and appends the children it creates to parity (L + 1) & 1.  Their
-// lengths live in THREE rotating counter rows, ctrl->cnt[L % 3][class]: while level L runs, row (L + 2) % 3 -- last read two levels ago --
-// is zeroed on a side stream, so no reset sits between two levels.  Kernels get "next" = list parity | counter row << 8 of the level they feed.
+// lengths live in THREE rotating counter rows, ctrl->cnt[L % 3][class]: when level L ends, its own row -- the host has its copy, the
+// kernels got their counts as arguments -- is zeroed by level_mark, so no reset sits between two levels.  Kernels get "next" = list parity |
+// counter row << 8 of the level they feed.
 struct alignas(128) Pad32 { uint32_t v; uint32_t pad[31]; };        // one counter per 128-B line: atomics on one line serialise, whichever word they hit
-struct Ctrl { Pad32 n_nodes, n_chunks, cnt[3][kClasses + 1], pool_alloc, sub_nodes; };   // cnt[parity][kClasses]: centroid-range records handed to that level's big nodes (big_finish); pool_*: nodes of the subtrees build_subtree_tiny finishes on its own
+struct Ctrl { Pad32 n_nodes, n_chunks, cnt[3][kClasses + 1], pool_alloc, sub_nodes, arrived; };   // cnt[parity][kClasses]: centroid-range records handed to that level's big nodes (big_finish); pool_*: nodes of the subtrees build_subtree_tiny finishes on its own; arrived: level_mark
 struct Lists { uint32_t *l[2][kClasses]; };
+// What the host needs of a level to size the next one, in pinned host memory (two slots, alternating): the counters, then the flag.
+struct LevelSnap { uint32_t n_nodes, sub_nodes, cnt[kClasses + 1]; uint32_t pad[32 - 3 - kClasses]; volatile uint32_t flag; uint32_t pad2[31]; };
+
+// The level's barrier.  A level's kernels run on up to four streams; joining them through the runtime (an event wait, the null stream,
+// a blocking copy) costs 45..90 us per level on this stack -- tools/calib/level_sync.hip -- because every cross-queue dependency is a
+// barrier packet on a completion signal.  Instead every stream that got work ends its level with this one-wave kernel: stream order
+// puts it behind the stream's kernels, a device atomic finds the one that arrives last, and that one hands the level's counters to
+// the host through pinned memory and raises the flag the host polls (~20 us per level, launch latency included).
+__global__ __launch_bounds__(64) void level_mark(Ctrl *ctrl, uint32_t expect, uint32_t row_next, uint32_t row_done, LevelSnap *snap, uint32_t flag) {
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(&ctrl->arrived.v, 1u) == expect - 1u ? 1u : 0u; }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const uint32_t t = threadIdx.x;
+    if (t <= kClasses) {
+        snap->cnt[t] = __hip_atomic_load(&ctrl->cnt[row_next][t].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctrl->cnt[row_done][t].v = 0u;
+    } else if (t == kClasses + 1u) snap->n_nodes = __hip_atomic_load(&ctrl->n_nodes.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (t == kClasses + 2u) snap->sub_nodes = __hip_atomic_load(&ctrl->sub_nodes.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (t == kClasses + 3u) ctrl->arrived.v = 0u;
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) snap->flag = flag;
+}
 
 struct alignas(16) Proxy {                                            // 32 B = two 16-B words
     float lo[3]; uint32_t idx; float hi[3]; uint32_t pad;
@@ -1049,9 +1077,33 @@ __global__ __launch_bounds__(64) void big_scan(BigState *bs, ChunkInfo *ch, cons
         acc += __shfl(x, 63);
     }
 }
+// Ranks of the set flags among kE * kT elements per step, element (j, t) = j * kT + t: one ballot per j, the four waves' totals
+// through LDS, ONE barrier per step (the table is double-buffered by step parity) -- and kE loads per thread in flight before it.
+template <int kE> struct StepRanks { uint32_t cnt[2][kE][4]; };
+template <int kE> __device__ __forceinline__ void step_ranks(const bool (&f)[kE], uint32_t (&rank)[kE], uint32_t *total, StepRanks<kE> *sr, uint32_t step) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    unsigned long long m[kE];
+#pragma unroll
+    for (int j = 0; j < kE; j++) m[j] = __ballot(f[j]);
+    uint32_t (*tab)[4] = sr->cnt[step & 1u];
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < kE; j++) tab[j][w] = (uint32_t)__popcll(m[j]);
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < kE; j++) {
+        const uint32_t c0 = tab[j][0], c1 = tab[j][1], c2 = tab[j][2], c3 = tab[j][3];
+        rank[j] = run + (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u) + mask_rank(m[j]);
+        run += c0 + c1 + c2 + c3;
+    }
+    *total = run;
+}
 __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, uint32_t *hole_pos, uint32_t *tail_pos,
                                                const Ctrl *ctrl) {
-    __shared__ uint32_t s_warp[4];
+    constexpr int kE = 8;
+    __shared__ StepRanks<kE> s_sr;
     if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
     const BigState *b = bs + c.big;
@@ -1059,22 +1111,27 @@ __global__ __launch_bounds__(kT) void big_fill(const BigState *bs, const ChunkIn
     const Proxy *in = pin + b->first + c.off;
     uint32_t *hp = hole_pos + b->first, *tp = tail_pos + b->first;
     const int axis = b->axis; const float pos = b->splitpos; const uint32_t k = b->k;
-    uint32_t hb = c.hole_base, tb = c.tail_base;
-    for (uint32_t base = 0; base < c.len; base += kT) {                 // holes: increasing p
-        const uint32_t i = base + threadIdx.x, p = c.off + i;
-        const uint32_t f = (i < c.len && p < k && !(in[i].cax(axis) < pos)) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
-        if (f) hp[hb + r] = p;
+    const uint32_t n_lo = c.off < k ? (k - c.off < c.len ? k - c.off : c.len) : 0u;     // the chunk's elements at positions < k
+    const uint32_t n_hi = c.len - n_lo;
+    uint32_t hb = c.hole_base, tb = c.tail_base, step = 0;
+    for (uint32_t base = 0; base < n_lo; base += kT * kE, step++) {      // holes: increasing p
+        bool f[kE];
+#pragma unroll
+        for (int j = 0; j < kE; j++) { const uint32_t i = base + (uint32_t)j * kT + threadIdx.x; f[j] = i < n_lo && !(in[i].cax(axis) < pos); }
+        uint32_t rank[kE], tot;
+        step_ranks(f, rank, &tot, &s_sr, step);
+#pragma unroll
+        for (int j = 0; j < kE; j++) if (f[j]) hp[hb + rank[j]] = c.off + base + (uint32_t)j * kT + threadIdx.x;
         hb += tot;
     }
-    for (uint32_t base = 0; base < c.len; base += kT) {                 // tail "<": decreasing p
-        const uint32_t q = base + threadIdx.x;
-        const uint32_t i = c.len - 1u - q, p = c.off + i;
-        const uint32_t f = (q < c.len && p >= k && (in[i].cax(axis) < pos)) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
-        if (f) tp[tb + r] = p;
+    for (uint32_t base = 0; base < n_hi; base += kT * kE, step++) {      // tail "<": decreasing p
+        bool f[kE];
+#pragma unroll
+        for (int j = 0; j < kE; j++) { const uint32_t q = base + (uint32_t)j * kT + threadIdx.x; f[j] = q < n_hi && (in[c.len - 1u - q].cax(axis) < pos); }
+        uint32_t rank[kE], tot;
+        step_ranks(f, rank, &tot, &s_sr, step);
+#pragma unroll
+        for (int j = 0; j < kE; j++) if (f[j]) tp[tb + rank[j]] = c.off + c.len - 1u - (base + (uint32_t)j * kT + threadIdx.x);
         tb += tot;
     }
 }
@@ -1098,7 +1155,8 @@ struct SideAcc {
 };
 __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, Proxy *__restrict__ pout,
                                                   const uint32_t *hole_pos, const uint32_t *tail_pos, const Ctrl *ctrl) {
-    __shared__ uint32_t s_warp[4];
+    constexpr int kE = 4;
+    __shared__ StepRanks<kE> s_sr;
     __shared__ uint32_t s_ckey[2][6], s_ccen[2][6];
     if (blockIdx.x >= ctrl->n_chunks.v) return;
     const ChunkInfo c = ch[blockIdx.x];
@@ -1114,40 +1172,51 @@ __global__ __launch_bounds__(kT) void big_scatter(BigState *bs, const ChunkInfo 
     // known here).  One accumulator set per side, indexed by constants only -- a `[side]` index would send the arrays to scratch.
     SideAcc A, B;
     const uint32_t t_last = n_holes ? tp[n_holes - 1u] : n;
-    uint32_t hb = c.hole_base;
-    for (uint32_t base = 0; base < c.len; base += kT) {                 // positions < k, increasing
-        const uint32_t i = base + threadIdx.x, p = c.off + i;
-        const bool valid = i < c.len && p < k;
-        Proxy e;
-        uint32_t f = 0;
-        if (valid) { e = in[i]; f = !(e.cax(axis) < pos) ? 1u : 0u; }
-        uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
-        if (valid) {
-            uint32_t dest = p;
-            if (f) { const uint32_t m = hb + r; dest = (m ? tp[m - 1u] : n) - 1u; }
-            out[dest] = e;
-            if (f) B.add(e); else A.add(e);
+    const uint32_t n_lo = c.off < k ? (k - c.off < c.len ? k - c.off : c.len) : 0u;     // the chunk's elements at positions < k
+    const uint32_t n_hi = c.len - n_lo;
+    uint32_t hb = c.hole_base, tb = c.tail_base, step = 0;
+    for (uint32_t base = 0; base < n_lo; base += kT * kE, step++) {      // positions < k, increasing
+        Proxy e[kE];
+        bool f[kE], valid[kE];
+#pragma unroll
+        for (int j = 0; j < kE; j++) {
+            const uint32_t i = base + (uint32_t)j * kT + threadIdx.x;
+            valid[j] = i < n_lo; f[j] = false;
+            if (valid[j]) { e[j] = in[i]; f[j] = !(e[j].cax(axis) < pos); }
+        }
+        uint32_t rank[kE], tot;
+        step_ranks(f, rank, &tot, &s_sr, step);
+#pragma unroll
+        for (int j = 0; j < kE; j++) {
+            if (!valid[j]) continue;
+            uint32_t dest = c.off + base + (uint32_t)j * kT + threadIdx.x;
+            if (f[j]) { const uint32_t m = hb + rank[j]; dest = (m ? tp[m - 1u] : n) - 1u; }
+            out[dest] = e[j];
+            if (f[j]) B.add(e[j]); else A.add(e[j]);
         }
         hb += tot;
     }
-    uint32_t tb = c.tail_base;
-    for (uint32_t base = 0; base < c.len; base += kT) {                 // positions >= k, decreasing
-        const uint32_t q = base + threadIdx.x;
-        const uint32_t i = c.len - 1u - q, p = c.off + i;
-        const bool valid = q < c.len && p >= k;
-        Proxy e;
-        uint32_t f = 0;
-        if (valid) { e = in[i]; f = (e.cax(axis) < pos) ? 1u : 0u; }
-        uint32_t tot;
-        const uint32_t r = block_exscan(f, s_warp, &tot);
-        if (valid) {
+    for (uint32_t base = 0; base < n_hi; base += kT * kE, step++) {      // positions >= k, decreasing
+        Proxy e[kE];
+        bool f[kE], valid[kE];
+#pragma unroll
+        for (int j = 0; j < kE; j++) {
+            const uint32_t q = base + (uint32_t)j * kT + threadIdx.x;
+            valid[j] = q < n_hi; f[j] = false;
+            if (valid[j]) { e[j] = in[c.len - 1u - q]; f[j] = e[j].cax(axis) < pos; }
+        }
+        uint32_t rank[kE], tot;
+        step_ranks(f, rank, &tot, &s_sr, step);
+#pragma unroll
+        for (int j = 0; j < kE; j++) {
+            if (!valid[j]) continue;
+            const uint32_t p = c.off + c.len - 1u - (base + (uint32_t)j * kT + threadIdx.x);
             uint32_t dest;
-            if (f) dest = hp[tb + r];
+            if (f[j]) dest = hp[tb + rank[j]];
             else if (p > t_last) dest = p - 1u;
             else dest = (p == k) ? (t_last - 1u) : (p - 1u);
-            out[dest] = e;
-            if (f) A.add(e); else B.add(e);
+            out[dest] = e[j];
+            if (f[j]) A.add(e[j]); else B.add(e[j]);
         }
         tb += tot;
     }
@@ -1276,7 +1345,8 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     uint32_t *d_order = nullptr;
     PoolNode *d_pool = nullptr;
     uint32_t *d_hp = nullptr, *d_tp = nullptr, *d_root = nullptr, *d_cbeg = nullptr, *d_lists = nullptr, *d_crange = nullptr;
-    Ctrl *d_ctrl = nullptr, *h_ctrl = nullptr;
+    Ctrl *d_ctrl = nullptr;
+    LevelSnap *h_snap = nullptr;                            // pinned, written by level_mark
     BigState *d_big = nullptr;
     ChunkInfo *d_chunks = nullptr;
     ChunkBins *d_cbins = nullptr;
@@ -1290,7 +1360,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         for (hipStream_t x : all) if (x) (void)hipStreamDestroy(x);
         void *p[] = {d_px[0], d_px[1], d_bn, d_nodes, d_order, d_pool, d_hp, d_tp, d_ctrl, d_root, d_cbeg, d_big, d_chunks, d_cbins, d_crange, d_lists};
         for (void *q : p) if (q) (void)hipFree(q);
-        if (h_ctrl) (void)hipHostFree(h_ctrl);
+        if (h_snap) (void)hipHostFree(h_snap);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
@@ -1305,7 +1375,8 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     HIP_TRY(hipMalloc((void **)&d_hp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_tp, (size_t)n_tris * 4));
     HIP_TRY(hipMalloc((void **)&d_ctrl, sizeof(Ctrl)));
-    HIP_TRY(hipHostMalloc((void **)&h_ctrl, sizeof(Ctrl), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&h_snap, 2 * sizeof(LevelSnap), hipHostMallocDefault));
+    memset(h_snap, 0, 2 * sizeof(LevelSnap));
     // work lists: a level has at most min(2^level, n_tris) nodes; a class list never holds more nodes than triangles / its
     // smallest node... sized by the simple bound n_tris + 1 per (parity, class)
     const size_t list_cap = (size_t)n_tris + 1u;
@@ -1353,9 +1424,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     uint32_t parity = 0, row = 0;                       // list parity = level & 1, counter row = level % 3
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
-        const uint32_t next = (parity ^ 1u) | (((row + 1u) % 3u) << 8);
-        // the counter row of level + 2 was last read two levels ago: zero it now, beside this level's kernels
-        HIP_TRY(hipMemsetAsync(&d_ctrl->cnt[(row + 2u) % 3u][0], 0, (kClasses + 1) * sizeof(Pad32), ss));
+        const uint32_t row_next = (row + 1u) % 3u, next = (parity ^ 1u) | (row_next << 8);
         const uint32_t nb = hc.cnt[row][CLS_BIG].v;
         if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk);
                                                         // its own stream: these 9 launches overlap the level's block / wave / tiny kernels
@@ -1386,11 +1455,36 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         if (ntin) hipLaunchKernelGGL(build_level_tiny, dim3((ntin + 63u) / 64u), dim3(64), 0, st, d_bn, ls.l[parity][CLS_TINY], ntin, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
         if (nsub) hipLaunchKernelGGL(build_subtree_tiny, dim3((nsub + 63u) / 64u), dim3(64), 0, ss, d_bn, ls.l[parity][CLS_SUB], nsub, d_px[cur], d_px[0], d_px[1], d_pool, d_ctrl);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(h_ctrl, d_ctrl, sizeof hc, hipMemcpyDeviceToHost));        // pinned target; also the level's barrier
-        hc = *h_ctrl;
+        {   // the level's barrier and the next level's counts: level_mark on every stream that got work, then poll its flag
+            hipStream_t used[4];
+            uint32_t n_used = 0;
+            if (nwm) used[n_used++] = sw;
+            if (nwl || nwa || nws || ng32 || ng16) used[n_used++] = sw2;
+            if (nb) used[n_used++] = sg;
+            if (ntin || nsub) used[n_used++] = ss;
+            for (int c = 0; c <= (int)kClasses; c++) hc.cnt[row][c].v = 0u;
+            if (n_used) {
+                const size_t lvl = lvl_begin.size();                    // level + 1: never 0
+                LevelSnap *snap = h_snap + (lvl & 1u);
+                for (uint32_t i = 0; i < n_used; i++) hipLaunchKernelGGL(level_mark, dim3(1), dim3(64), 0, used[i], d_ctrl, n_used, row_next, row, snap, (uint32_t)lvl);
+                HIP_TRY(hipGetLastError());
+                const auto t_spin = std::chrono::steady_clock::now();
+                for (uint32_t spins = 0; snap->flag != (uint32_t)lvl; spins++) {
+                    if ((spins & 0xfffffu) == 0xfffffu && std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(20)) {
+                        const hipError_t e = hipDeviceSynchronize();    // a kernel that faulted never raises the flag
+                        cleanup();
+                        mipt_internal_set_error(e != hipSuccess ? hipGetErrorString(e) : "mipt_bvh_build_device: level barrier timed out");
+                        return MIPT_ERR_HIP;
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                hc.n_nodes.v = snap->n_nodes; hc.sub_nodes.v = snap->sub_nodes;
+                for (int c = 0; c <= (int)kClasses; c++) hc.cnt[row_next][c].v = snap->cnt[c];
+            }
+        }
         const uint32_t total = hc.n_nodes.v;
         if (total > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-        begin = end; end = total; cur ^= 1; parity ^= 1u; row = (row + 1u) % 3u;
+        begin = end; end = total; cur ^= 1; parity ^= 1u; row = row_next;
         if (lvl_begin.size() > 4096) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: tree deeper than 4096 levels"); return MIPT_ERR_BVH; }
     }
     const uint32_t n_bn = end;                                  // nodes built level by level; the finished subtrees' nodes live in the pool
