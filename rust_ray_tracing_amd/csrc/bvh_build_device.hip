@@ -194,20 +194,27 @@ __global__ void make_proxies(const MiptTriangle *tris, uint32_t n, Proxy *px, ui
     if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0xffffffffu; s_hi[threadIdx.x] = 0u; s_clo[threadIdx.x] = 0xffffffffu; s_chi[threadIdx.x] = 0u; }
     __syncthreads();
     float cmn[3] = {F32_MAX, F32_MAX, F32_MAX}, cmx[3] = {-F32_MAX, -F32_MAX, -F32_MAX};      // fminf / fmaxf skip a NaN centroid, as the reference's loop does
+    uint32_t klo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, khi[3] = {0u, 0u, 0u};          // the root box as keys, per thread (six LDS atomics per triangle on six addresses were most of this kernel)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Proxy p;
         p.idx = i; p.pad = 0u;
+#pragma unroll
         for (int a = 0; a < 3; a++) {
             float mn = F32_MAX, mx = -F32_MAX;                                          // scene.rs:115-123, bvh.rs:185-194
+#pragma unroll
             for (int v = 0; v < 3; v++) { const float q = (&tris[i].vertices[v].position.x)[a]; mn = fminf(mn, q); mx = fmaxf(mx, q); }
             p.lo[a] = mn; p.hi[a] = mx;                                                 // scene.rs:125: see Proxy::c
-            atomicMin(&s_lo[a], fkey(mn)); atomicMax(&s_hi[a], fkey(mx));
+            const uint32_t kl = fkey(mn), kh = fkey(mx);
+            klo[a] = kl < klo[a] ? kl : klo[a]; khi[a] = kh > khi[a] ? kh : khi[a];
             const float c = (mn + mx) / 2.0f;
             cmn[a] = fminf(cmn[a], c); cmx[a] = fmaxf(cmx[a], c);
         }
         px[i] = p;
     }
-    for (int a = 0; a < 3; a++) { atomicMin(&s_clo[a], fkey(cmn[a])); atomicMax(&s_chi[a], fkey(cmx[a])); }
+    for (int a = 0; a < 3; a++) {
+        atomicMin(&s_lo[a], klo[a]); atomicMax(&s_hi[a], khi[a]);
+        atomicMin(&s_clo[a], fkey(cmn[a])); atomicMax(&s_chi[a], fkey(cmx[a]));
+    }
     __syncthreads();
     if (threadIdx.x < 3) {
         atomicMin(&rootkeys[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&rootkeys[3 + threadIdx.x], s_hi[threadIdx.x]);
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(64) void build_level_tiny(BNode *bn, const uint32_t
 // runs the reference's recursion to the end -- split_node (bvh.rs:56-136) with evaluate_sah (:138-161) as written, the partition
 // loop (:99-108) in place, children pushed in pairs and then left before right (:131-135) -- with an explicit stack.  The
 // subtree's nodes go to a pool in exactly the order the reference appends them, so their final indices are base(X) + local index
-// (desc(X) = [A, B] ++ desc(A) ++ desc(B)); sizes_level / bases_level treat X as a node with `size` descendants and emit_nodes
+// (desc(X) = [A, B] ++ desc(A) ++ desc(B)); sizes_level / bases_level treat X as a node with `size` descendants and place_node
 // copies the pool block with its child indices re-based.  A child's box is recomputed from its range when the child is popped:
 // the same min/max over the same proxies in the same order as the parent's own child-box loops (bvh.rs:115-130), so the same bits.
 struct PoolNode { float lo[3]; uint32_t a; float hi[3]; uint32_t n; };            // a: local index of the left child (inner) / first triangle (leaf)
@@ -885,16 +892,16 @@ struct ChunkBins { uint32_t cnt[3][8]; };   // per chunk: elements per (axis, bi
 // The node's centroid range (bvh.rs:67-77) is already known: the root's from make_proxies, every other big node's from its parent's
 // big_scatter (big_finish left the record index in the node's `dfs` field, which the final renumbering overwrites).  So the planes
 // (bvh.rs:82-84) are computed here and the level needs no pass of its own for them.
-__global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, const uint32_t *ids, uint32_t nb, ChunkInfo *ch,
-                                                uint32_t *chunk_begin, Ctrl *ctrl, const uint32_t *rootkeys, const uint32_t *crange) {
-    __shared__ uint32_t s_warp[4];
+constexpr int kSetupT = 1024;
+__global__ __launch_bounds__(kSetupT) void big_setup(BigState *bs, const BNode *bn, const uint32_t *ids, uint32_t nb, ChunkInfo *ch,
+                                                     uint32_t *chunk_begin, Ctrl *ctrl, const uint32_t *rootkeys, const uint32_t *crange) {
+    __shared__ uint32_t s_warp[kSetupT / 64];
     uint32_t running = 0;
-    for (uint32_t base = 0; base < nb; base += kT) {
+    for (uint32_t base = 0; base < nb; base += kSetupT) {
         const uint32_t j = base + threadIdx.x;
         uint32_t my_chunks = 0;
-        BNode nd;
         if (j < nb) {
-            nd = bn[ids[j]];
+            const BNode nd = bn[ids[j]];
             BigState &s = bs[j];                                                         // written in place: a local copy of the 700-byte record lives in scratch
             s.node = ids[j]; s.first = nd.first; s.n = nd.n;
             s.split = 0; s.axis = 0; s.splitpos = 0.0f; s.k = 0u; s.n_holes = 0u; s.k_known = 0; s.plane = 0;
@@ -914,19 +921,23 @@ __global__ __launch_bounds__(kT) void big_setup(BigState *bs, const BNode *bn, c
             my_chunks = (nd.n + kChunk - 1u) / kChunk;
         }
         uint32_t tot;
-        const uint32_t off0 = running + block_exscan(my_chunks, s_warp, &tot);
-        if (j < nb) {
-            chunk_begin[j] = off0;
-            for (uint32_t c = 0; c < my_chunks; c++) {
-                ChunkInfo ci;
-                ci.big = j; ci.off = c * kChunk; ci.len = nd.n - ci.off < kChunk ? nd.n - ci.off : kChunk;
-                ci.hole_cnt = ci.tail_cnt = ci.hole_base = ci.tail_base = ci.pad = 0u;
-                ch[off0 + c] = ci;
-            }
-        }
+        const uint32_t off0 = running + block_exscan<kSetupT / 64>(my_chunks, s_warp, &tot);
+        if (j < nb) chunk_begin[j] = off0;
         running += tot;
     }
     if (threadIdx.x == 0) { chunk_begin[nb] = running; ctrl->n_chunks.v = running; }
+    __threadfence_block();
+    __syncthreads();
+    // the chunk table, all threads: chunk g belongs to the last node whose first chunk is <= g (the root alone has 1 221 chunks)
+    for (uint32_t g = threadIdx.x; g < running; g += kSetupT) {
+        uint32_t lo = 0, hi = nb;                                                        // chunk_begin[lo] <= g < chunk_begin[hi]
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (chunk_begin[mid] <= g) lo = mid; else hi = mid; }
+        const uint32_t n = bs[lo].n, c = g - chunk_begin[lo];
+        ChunkInfo ci;
+        ci.big = lo; ci.off = c * kChunk; ci.len = n - ci.off < kChunk ? n - ci.off : kChunk;
+        ci.hole_cnt = ci.tail_cnt = ci.hole_base = ci.tail_base = ci.pad = 0u;
+        ch[g] = ci;
+    }
 }
 __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch, ChunkBins *cbins, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
     __shared__ uint32_t s_keyc[kCopies][3][8][6];
@@ -1256,14 +1267,33 @@ __global__ void sizes_level(BNode *bn, uint32_t begin, uint32_t end) {          
         bn[i].size = (l == kNone) ? 0u : 2u + bn[l].size + bn[l + 1].size;
     }
 }
-__global__ void bases_level(BNode *bn, uint32_t begin, uint32_t end) {              // top-down: desc(X) = [A, B] ++ desc(A) ++ desc(B)
-    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
-        const uint32_t l = bn[i].left;
-        if (l == kNone || (l & kSubFlag)) continue;
-        const uint32_t b = bn[i].base;
-        bn[l].dfs = b; bn[l + 1].dfs = b + 1u;
-        bn[l].base = b + 2u; bn[l + 1].base = b + 2u + bn[l].size;
+// Top-down: desc(X) = [A, B] ++ desc(A) ++ desc(B).  A node's own place (dfs) and its descendants' block (base) were set by its
+// parent one level up, so the node is also WRITTEN here, in the reference's 32-byte format (a pass of its own over all nodes before).
+__device__ __forceinline__ void place_node(BNode *bn, uint32_t i, const PoolNode *__restrict__ pool, MiptNode *nodes) {
+    const BNode b = bn[i];
+    MiptNode nd;
+    nd.bounds_min = {b.lo[0], b.lo[1], b.lo[2]}; nd.bounds_max = {b.hi[0], b.hi[1], b.hi[2]};
+    if (b.left == kNone) { nd.first_tri_or_child = b.first; nd.num_tris = b.n; }
+    else { nd.first_tri_or_child = b.base; nd.num_tris = 0; }
+    nodes[b.dfs] = nd;
+    if (b.left == kNone) return;
+    if (b.left & kSubFlag) {                                                       // its subtree: pool block -> nodes[base ...], child indices re-based
+        const PoolNode *src = pool + (b.left & ~kSubFlag);
+        for (uint32_t j = 0; j < b.size; j++) {
+            const PoolNode q = src[j];
+            MiptNode o;
+            o.bounds_min = {q.lo[0], q.lo[1], q.lo[2]}; o.bounds_max = {q.hi[0], q.hi[1], q.hi[2]};
+            o.first_tri_or_child = q.n ? q.a : b.base + q.a; o.num_tris = q.n;
+            nodes[b.base + j] = o;
+        }
+        return;
     }
+    const uint32_t l = b.left;
+    bn[l].dfs = b.base; bn[l + 1].dfs = b.base + 1u;
+    bn[l].base = b.base + 2u; bn[l + 1].base = b.base + 2u + bn[l].size;
+}
+__global__ void bases_level(BNode *bn, uint32_t begin, uint32_t end, const PoolNode *__restrict__ pool, MiptNode *nodes) {
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) place_node(bn, i, pool, nodes);
 }
 // The same two passes for a RUN of consecutive small levels in one launch (one workgroup, a barrier between levels): the top of the tree
 // and its last few levels hold a handful of nodes each, and a launch per level and pass was 58 launches ~ 0.9 ms of a 17-ms build.
@@ -1279,36 +1309,10 @@ __global__ __launch_bounds__(1024) void sizes_run(BNode *bn, LevelRun r) {      
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(1024) void bases_run(BNode *bn, LevelRun r) {                // top-down
+__global__ __launch_bounds__(1024) void bases_run(BNode *bn, LevelRun r, const PoolNode *__restrict__ pool, MiptNode *nodes) {   // top-down
     for (uint32_t i = 0; i < r.n; i++) {
-        for (uint32_t j = r.b[i] + threadIdx.x; j < r.b[i + 1]; j += blockDim.x) {
-            const uint32_t l = bn[j].left;
-            if (l == kNone || (l & kSubFlag)) continue;
-            const uint32_t b = bn[j].base;
-            bn[l].dfs = b; bn[l + 1].dfs = b + 1u;
-            bn[l].base = b + 2u; bn[l + 1].base = b + 2u + bn[l].size;
-        }
+        for (uint32_t j = r.b[i] + threadIdx.x; j < r.b[i + 1]; j += blockDim.x) place_node(bn, j, pool, nodes);
         __syncthreads();
-    }
-}
-__global__ void emit_nodes(const BNode *bn, uint32_t n_nodes, const PoolNode *__restrict__ pool, MiptNode *nodes) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x) {
-        const BNode b = bn[i];
-        MiptNode nd;
-        nd.bounds_min = {b.lo[0], b.lo[1], b.lo[2]}; nd.bounds_max = {b.hi[0], b.hi[1], b.hi[2]};
-        if (b.left == kNone) { nd.first_tri_or_child = b.first; nd.num_tris = b.n; }
-        else { nd.first_tri_or_child = b.base; nd.num_tris = 0; }
-        nodes[b.dfs] = nd;
-        if (b.left != kNone && (b.left & kSubFlag)) {                              // its subtree: pool block -> nodes[base ...], child indices re-based
-            const PoolNode *src = pool + (b.left & ~kSubFlag);
-            for (uint32_t j = 0; j < b.size; j++) {
-                const PoolNode q = src[j];
-                MiptNode o;
-                o.bounds_min = {q.lo[0], q.lo[1], q.lo[2]}; o.bounds_max = {q.hi[0], q.hi[1], q.hi[2]};
-                o.first_tri_or_child = q.n ? q.a : b.base + q.a; o.num_tris = q.n;
-                nodes[b.base + j] = o;
-            }
-        }
     }
 }
 __global__ void extract_order(const Proxy *px, uint32_t n, uint32_t *order) {        // reordered[t] = original[order[t]]
@@ -1432,7 +1436,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
             if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             const dim3 gb((nb + 63) / 64), tb(64);
             if (hc.cnt[row][kClasses].v > big_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
-            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl, d_root, d_crange + (size_t)parity * big_cap * 6);
+            hipLaunchKernelGGL(big_setup, dim3(1), dim3(kSetupT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl, d_root, d_crange + (size_t)parity * big_cap * 6);
             hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_cbins, d_px[cur], d_ctrl);
             hipLaunchKernelGGL(big_choose, gb, tb, 0, sg, d_big, nb);
             hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
@@ -1491,13 +1495,14 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     const uint32_t n_nodes = n_bn + hc.sub_nodes.v;
     lvl_begin.push_back(n_bn);
     if (n_nodes > max_nodes) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: node overflow"); return MIPT_ERR_BVH; }
-    {   // subtree sizes bottom-up, then depth-first bases top-down: runs of small levels in one launch each, wide levels one by one
+    hipLaunchKernelGGL(extract_order, dim3(2048), dim3(256), 0, sw, d_px[cur], n_tris, d_order);      // beside the two tree passes below (every stream is idle here: the last level's barrier has been seen)
+    {   // subtree sizes bottom-up, then depth-first bases top-down (which also writes the nodes): runs of small levels in one launch each, wide levels one by one
         const int n_lvl = (int)lvl_begin.size() - 1;
         auto small = [&](int l) { return lvl_begin[(size_t)l + 1] - lvl_begin[(size_t)l] <= kRunNodes; };
         for (int l = n_lvl - 1; l >= 0;) {
             if (!small(l)) {
                 const uint32_t b = lvl_begin[(size_t)l], e = lvl_begin[(size_t)l + 1];
-                hipLaunchKernelGGL(sizes_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+                hipLaunchKernelGGL(sizes_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, sg, d_bn, b, e);
                 l--;
                 continue;
             }
@@ -1506,13 +1511,13 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
             LevelRun r;
             r.n = (uint32_t)(l - lo + 1);
             for (int i = 0; i <= l - lo + 1; i++) r.b[i] = lvl_begin[(size_t)(lo + i)];
-            hipLaunchKernelGGL(sizes_run, dim3(1), dim3(1024), 0, nullptr, d_bn, r);
+            hipLaunchKernelGGL(sizes_run, dim3(1), dim3(1024), 0, sg, d_bn, r);
             l = lo - 1;
         }
         for (int l = 0; l < n_lvl;) {
             if (!small(l)) {
                 const uint32_t b = lvl_begin[(size_t)l], e = lvl_begin[(size_t)l + 1];
-                hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, nullptr, d_bn, b, e);
+                hipLaunchKernelGGL(bases_level, dim3((e - b + 255) / 256 < 2048 ? (e - b + 255) / 256 : 2048), dim3(256), 0, sg, d_bn, b, e, d_pool, d_nodes);
                 l++;
                 continue;
             }
@@ -1521,12 +1526,10 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
             LevelRun r;
             r.n = (uint32_t)(hi - l + 1);
             for (int i = 0; i <= hi - l + 1; i++) r.b[i] = lvl_begin[(size_t)(l + i)];
-            hipLaunchKernelGGL(bases_run, dim3(1), dim3(1024), 0, nullptr, d_bn, r);
+            hipLaunchKernelGGL(bases_run, dim3(1), dim3(1024), 0, sg, d_bn, r, d_pool, d_nodes);
             l = hi + 1;
         }
     }
-    hipLaunchKernelGGL(emit_nodes, dim3(2048), dim3(256), 0, nullptr, d_bn, n_bn, d_pool, d_nodes);
-    hipLaunchKernelGGL(extract_order, dim3(2048), dim3(256), 0, nullptr, d_px[cur], n_tris, d_order);
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     float ms = 0.0f;

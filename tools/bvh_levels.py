@@ -10,7 +10,7 @@ for s, e, d, n in rows: tot[n] += d; cnt[n] += 1
 for n, v in tot.most_common(16): print(f"{n:32s} {v/1e3:8.2f} ms  {cnt[n]} launches")
 # A level ends with level_mark kernels (one per stream that had work).  The level's last mark is the one with nothing running when it
 # ends and nothing starting for the next 7 us (the host's round trip); marks of streams that finish early sit inside the level.
-skip = ("sizes_level", "bases_level", "emit_nodes", "gather_tris", "make_proxies", "init_root")
+skip = ("sizes_level", "bases_level", "sizes_run", "bases_run", "extract_order", "emit_nodes", "gather_tris", "make_proxies", "init_root")
 work = [r for r in rows if not r[3].startswith("__amd") and r[3] not in skip and r[3] != "level_mark"]
 marks = [r for r in rows if r[3] == "level_mark"]
 bounds = []
