@@ -978,54 +978,58 @@ __global__ __launch_bounds__(kT) void big_bin(BigState *bs, const ChunkInfo *ch,
         (&cbins[blockIdx.x].cnt[0][0])[i] = v;
     }
 }
-__global__ void big_choose(BigState *bs, uint32_t nb) {                              // same expression order as build_level step 3
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per node; lane 0 picks the split.  If no plane was usable and the node splits all the same (a parent cost that is NaN or
+// infinite: `best >= parent` is false), the split position is 0.0 on axis 0 and k has to be counted: the wave does that here over the
+// whole node -- never seen on finite geometry, and a kernel of its own for it (one workgroup per chunk, leaving at once) sat in the
+// chain of every level, up to 190 us of it waiting for a free CU under the wave kernels.
+__global__ __launch_bounds__(64) void big_choose(BigState *bs, uint32_t nb, const Proxy *__restrict__ pin) {   // same expression order as wave_node's step 3
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= nb) return;
     BigState *b = bs + j;
-    const float parent_cost = (float)b->n * box_area(b->lo, b->hi);
-    float best_cost = F32_MAX, best_pos = 0.0f;
-    int best_axis = 0, best_plane = 0;
-    uint32_t best_k = kNone;
-    for (int a = 0; a < 3; a++) {
-        if (!b->use[a]) continue;
-        float rlo[8][3], rhi[8][3];
-        uint32_t rcnt[8];
-        float alo[3] = {F32_MAX, F32_MAX, F32_MAX}, ahi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-        uint32_t c = 0;
-        for (int k = 7; k >= 0; k--) {
-            for (int q = 0; q < 3; q++) { alo[q] = fminf(alo[q], funkey(b->key[a][k][q])); ahi[q] = fmaxf(ahi[q], funkey(b->key[a][k][3 + q])); }
-            c += b->cnt[a][k];
-            for (int q = 0; q < 3; q++) { rlo[k][q] = alo[q]; rhi[k][q] = ahi[q]; }
-            rcnt[k] = c;
+    int need_count = 0, axis = 0;
+    float pos = 0.0f;
+    if (lane == 0) {
+        const float parent_cost = (float)b->n * box_area(b->lo, b->hi);
+        float best_cost = F32_MAX, best_pos = 0.0f;
+        int best_axis = 0, best_plane = 0;
+        uint32_t best_k = kNone;
+        for (int a = 0; a < 3; a++) {
+            if (!b->use[a]) continue;
+            float rlo[8][3], rhi[8][3];
+            uint32_t rcnt[8];
+            float alo[3] = {F32_MAX, F32_MAX, F32_MAX}, ahi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            uint32_t c = 0;
+            for (int k = 7; k >= 0; k--) {
+                for (int q = 0; q < 3; q++) { alo[q] = fminf(alo[q], funkey(b->key[a][k][q])); ahi[q] = fmaxf(ahi[q], funkey(b->key[a][k][3 + q])); }
+                c += b->cnt[a][k];
+                for (int q = 0; q < 3; q++) { rlo[k][q] = alo[q]; rhi[k][q] = ahi[q]; }
+                rcnt[k] = c;
+            }
+            float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
+            uint32_t lc = 0;
+            for (int i = 1; i < 8; i++) {
+                for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(b->key[a][i - 1][q])); lhi[q] = fmaxf(lhi[q], funkey(b->key[a][i - 1][3 + q])); }
+                lc += b->cnt[a][i - 1];
+                const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
+                const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
+                if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; best_k = lc; best_plane = i; }
+            }
         }
-        float llo[3] = {F32_MAX, F32_MAX, F32_MAX}, lhi[3] = {-F32_MAX, -F32_MAX, -F32_MAX};
-        uint32_t lc = 0;
-        for (int i = 1; i < 8; i++) {
-            for (int q = 0; q < 3; q++) { llo[q] = fminf(llo[q], funkey(b->key[a][i - 1][q])); lhi[q] = fmaxf(lhi[q], funkey(b->key[a][i - 1][3 + q])); }
-            lc += b->cnt[a][i - 1];
-            const float cost = (float)lc * box_area(llo, lhi) + (float)rcnt[i] * box_area(rlo[i], rhi[i]);
-            const float split_cost = (cost > 0.0f) ? cost : F32_MAX;
-            if (split_cost < best_cost) { best_axis = a; best_pos = b->pos[a][i]; best_cost = split_cost; best_k = lc; best_plane = i; }
-        }
+        b->split = !(best_cost >= parent_cost);
+        b->axis = best_axis; b->splitpos = best_pos; b->plane = best_plane;
+        b->k_known = best_k != kNone;
+        if (b->k_known) b->k = best_k;
+        need_count = (b->split && !b->k_known) ? 1 : 0;
+        axis = best_axis; pos = best_pos;
     }
-    b->split = !(best_cost >= parent_cost);
-    b->axis = best_axis; b->splitpos = best_pos; b->plane = best_plane;
-    b->k_known = best_k != kNone;
-    if (b->k_known) b->k = best_k;
-}
-__global__ __launch_bounds__(kT) void big_count(BigState *bs, const ChunkInfo *ch, const Proxy *__restrict__ pin, const Ctrl *ctrl) {
-    __shared__ uint32_t s_warp[4];
-    if (blockIdx.x >= ctrl->n_chunks.v) return;
-    const ChunkInfo c = ch[blockIdx.x];
-    BigState *b = bs + c.big;
-    if (!b->split || b->k_known) return;
-    const Proxy *in = pin + b->first + c.off;
-    const int axis = b->axis; const float pos = b->splitpos;
+    need_count = __shfl(need_count, 0);
+    if (!need_count) return;
+    axis = __shfl(axis, 0); pos = __shfl(pos, 0);
+    const Proxy *in = pin + b->first;
     uint32_t cnt = 0;
-    for (uint32_t i = threadIdx.x; i < c.len; i += kT) cnt += (in[i].cax(axis) < pos) ? 1u : 0u;
-    uint32_t tot;
-    (void)block_exscan(cnt, s_warp, &tot);
-    if (threadIdx.x == 0 && tot) atomicAdd(&b->k, tot);
+    for (uint32_t i = lane; i < b->n; i += 64u) cnt += (in[i].cax(axis) < pos) ? 1u : 0u;
+    cnt = wave_sum(cnt);
+    if (lane == 0) b->k = cnt;
 }
 // holes (positions < k holding ">=") and tail "<" (positions >= k holding "<") per chunk.  With k taken from the winning plane's bin
 // counts the chunk's own counts say how many of its elements are "<" (bins below the plane: the planes increase with their index), so
@@ -1402,11 +1406,15 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     HIP_TRY(hipMalloc((void **)&d_chunks, (size_t)chunk_cap * sizeof(ChunkInfo)));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipStreamCreate(&sw));                          // blocking streams: ordered against the null stream's copies / launches
-    HIP_TRY(hipStreamCreate(&sw2));
-    HIP_TRY(hipStreamCreate(&sg));
-    HIP_TRY(hipStreamCreate(&ss));
-    hipStream_t const sw3 = sw2, st = ss;
+    {   // blocking streams: ordered against the null stream's copies / launches.  The chunked path is a chain of nine dependent launches:
+        // its stream gets the higher priority, so that a link of the chain is not left waiting for a CU under the wave kernels' workgroups
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRY(hipStreamCreateWithPriority(&sg, hipStreamDefault, prio_hi));
+        HIP_TRY(hipStreamCreateWithPriority(&sw, hipStreamDefault, prio_lo));
+        HIP_TRY(hipStreamCreateWithPriority(&sw2, hipStreamDefault, prio_lo));
+        HIP_TRY(hipStreamCreateWithPriority(&ss, hipStreamDefault, prio_lo));
+    }
     const uint32_t root_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 48, hipMemcpyHostToDevice));
     Ctrl hc;
@@ -1425,6 +1433,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     std::vector<uint32_t> lvl_begin;
     uint32_t begin = 0, end = 1;
     int cur = 0;
+    hipStream_t const sw3 = sw2, st = ss;
     uint32_t parity = 0, row = 0;                       // list parity = level & 1, counter row = level % 3
     while (begin < end) {                               // one round of launches per tree level; `end` strictly grows or the loop stops
         lvl_begin.push_back(begin);
@@ -1438,8 +1447,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
             if (hc.cnt[row][kClasses].v > big_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             hipLaunchKernelGGL(big_setup, dim3(1), dim3(kSetupT), 0, sg, d_big, d_bn, ls.l[parity][CLS_BIG], nb, d_chunks, d_cbeg, d_ctrl, d_root, d_crange + (size_t)parity * big_cap * 6);
             hipLaunchKernelGGL(big_bin, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_cbins, d_px[cur], d_ctrl);
-            hipLaunchKernelGGL(big_choose, gb, tb, 0, sg, d_big, nb);
-            hipLaunchKernelGGL(big_count, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_ctrl);
+            hipLaunchKernelGGL(big_choose, dim3(nb), dim3(64), 0, sg, d_big, nb, d_px[cur]);
             hipLaunchKernelGGL(big_count2, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_cbins, d_px[cur], d_ctrl);
             hipLaunchKernelGGL(big_scan, dim3(nb), dim3(64), 0, sg, d_big, d_chunks, d_cbeg, nb);
             hipLaunchKernelGGL(big_fill, dim3(nc), dim3(kT), 0, sg, d_big, d_chunks, d_px[cur], d_hp, d_tp, d_ctrl);
