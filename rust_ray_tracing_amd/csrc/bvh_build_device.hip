@@ -1251,6 +1251,7 @@ __global__ void big_finish(const BigState *bs, BNode *bn, Ctrl *ctrl, Lists ls, 
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nb || !bs[j].split) return;
     const BigState &s = bs[j];
+    if (s.k == 0u || s.k == s.n) return;                                // bvh.rs:110-113: everything on one side -- a leaf, AFTER the partition loop has reordered its triangles (the scatter did)
     const Box3 A{funkey(s.ckey[0][0]), funkey(s.ckey[0][1]), funkey(s.ckey[0][2]), funkey(s.ckey[0][3]), funkey(s.ckey[0][4]), funkey(s.ckey[0][5])};
     const Box3 B{funkey(s.ckey[1][0]), funkey(s.ckey[1][1]), funkey(s.ckey[1][2]), funkey(s.ckey[1][3]), funkey(s.ckey[1][4]), funkey(s.ckey[1][5])};
     const uint32_t base = emit_children(bn, ctrl, ls, next_parity, s.node, A, B, s.first, s.k, s.n);

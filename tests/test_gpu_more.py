@@ -599,6 +599,27 @@ def test_device_bvh_builder_random_soups(rrt):
         assert a.tobytes() == b.tobytes(), it
 
 
+@pytest.mark.parametrize("n", [7, 40, 300, 1500, 9000, 40000])
+def test_device_bvh_builder_overflowing_areas(rrt, n):
+    """Boxes whose surface area overflows f32: every plane costs inf, `best >= parent` (inf) is false all the same, so bvh.rs:94-108
+    splits at position 0.0 on axis 0 and k comes from counting -- the one path that does not take k from the bin counts.  Through
+    every size class of the device builder (the chunked one counts in big_choose)."""
+    from rust_ray_tracing_amd import TRIANGLE
+    rng = np.random.default_rng(n)
+    t = np.zeros(n, dtype=TRIANGLE)
+    p = rng.standard_normal((n, 1, 3)) * 3e19 + rng.standard_normal((n, 3, 3)) * 1e18
+    t["vertices"]["position"] = p.astype(np.float32)
+    host = rrt.Scene.from_arrays(t, [rrt.material_default()])
+    dev = rrt.Scene.from_arrays(t, [rrt.material_default()], build_bvh=False)
+    dev.build_bvh_device(0)
+    assert dev.tris.tobytes() == host.tris.tobytes()
+    a, b = host.bvh_nodes.copy(), dev.bvh_nodes.copy()
+    for k in ("bounds_min", "bounds_max"):
+        a[k] += np.float32(0); b[k] += np.float32(0)
+    assert a.tobytes() == b.tobytes()
+    assert len(a) >= 3                                                    # it did split
+
+
 def _chain_bvh(rrt, depth):
     """Hand-built BVH (the ABI accepts any well-formed tree): a chain in which every inner node has a FAR leaf child and a
     NEAR inner child for a ray along +x, so each level pushes one stack entry: stack occupancy = depth."""
