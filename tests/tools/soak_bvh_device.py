@@ -1,5 +1,5 @@
 """GPU box: device BVH builder vs host builder on many random triangle soups (sizes across every builder class, with ties,
-identical centroids, flat and degenerate triangles).  Prints the number of soups whose node array or triangle order differs; must be 0."""
+identical centroids, flat and degenerate triangles, boxes whose area overflows).  Prints the number of soups whose node array or triangle order differs; must be 0."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -13,6 +13,7 @@ for it in range(n_iter):
     kind = it % 6
     n = int(rng.integers(1, 600)) if kind < 2 else int(rng.integers(600, 9000)) if kind < 4 else int(rng.integers(9000, 120000))
     scale = float(rng.choice([1e-3, 1.0, 1e3]))
+    if it % 10 == 9: scale = 1e19                                              # surface areas overflow: no plane is usable, the split falls back to 0.0 on axis 0
     spread = float(rng.choice([0.05, 1.0, 20.0]))
     p = rng.standard_normal((n, 1, 3)) * scale * spread + rng.standard_normal((n, 3, 3)) * scale * rng.random((n, 1, 1))
     mode = it % 5
