@@ -1407,14 +1407,17 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
     HIP_TRY(hipMalloc((void **)&d_chunks, (size_t)chunk_cap * sizeof(ChunkInfo)));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    {   // blocking streams: ordered against the null stream's copies / launches.  The chunked path is a chain of nine dependent launches:
+    {   // blocking streams: ordered against the null stream's copies / launches.  The chunked path is a chain of eight dependent launches:
         // its stream gets the higher priority, so that a link of the chain is not left waiting for a CU under the wave kernels' workgroups
+        // (-0.5 ms).  The others stay at the default priority: a stream at a priority the process has not used yet costs a new hardware
+        // queue, 6-7 ms each the first time in a process (tools/setup_trace_first.py); creating them on a helper thread during the upload does
+        // not hide that -- the runtime serialises queue creation with the copies (tried: the upload grew by what the creation took).
         int prio_lo = 0, prio_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIP_TRY(hipStreamCreateWithPriority(&sg, hipStreamDefault, prio_hi));
-        HIP_TRY(hipStreamCreateWithPriority(&sw, hipStreamDefault, prio_lo));
-        HIP_TRY(hipStreamCreateWithPriority(&sw2, hipStreamDefault, prio_lo));
-        HIP_TRY(hipStreamCreateWithPriority(&ss, hipStreamDefault, prio_lo));
+        HIP_TRY(hipStreamCreate(&sw));
+        HIP_TRY(hipStreamCreate(&sw2));
+        HIP_TRY(hipStreamCreate(&ss));
     }
     const uint32_t root_init[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpy(d_root, root_init, 48, hipMemcpyHostToDevice));
