@@ -2,9 +2,11 @@
 // triangle order as the host restatement (bvh_build.cpp) and the reference.  SURVEY 8(f) rank 4.
 //
 // Level-synchronous.  Every level's nodes are sorted into classes as they are created (device-side lists, no empty
-// workgroups): > 2 048 triangles -> many workgroups per node, one per 8 192-element chunk (big_* kernels); 9..2 048 -> one WAVE
-// per node with its proxies in registers (three instantiations: <= 64, <= 512, <= 2 048); 5..8 -> one thread per node running the
-// reference's loops as written; <= 4 -> one thread finishes the node's whole subtree.  The steps of a split, in every class:
+// workgroups): > 2 048 triangles -> many workgroups per node, one per 8 192-element chunk (big_* kernels); 33..2 048 -> one WAVE
+// per node with its proxies in registers (four instantiations: <= 64, <= 128, <= 512, <= 2 048); 9..32 -> several nodes per wave
+// (16- and 32-lane groups); 5..8 -> one thread per node running the reference's loops as written; <= 4 -> one thread finishes the
+// node's whole subtree.  A level's kernels run on four streams and end in level_mark (the barrier: no runtime join, see there).
+// The steps of a split, in every class:
 //   1. centroid range per axis (f32 min/max are exact and order-independent; for the multi-workgroup path it is a by-product of
 //      the parent's scatter pass, the root's of make_proxies)
 //   2. "first plane the centroid is below" binning with the reference's own plane values and `<` comparisons
@@ -877,7 +879,7 @@ struct BigState {
     int split, axis;
     float splitpos;
     uint32_t k, n_holes;
-    int k_known;                   // k taken from the bin counts of the winning plane (big_choose); else big_count counts it
+    int k_known;                   // k taken from the bin counts of the winning plane (big_choose); else big_choose counts it
     int plane;                     // the winning plane's index 1..7 (bins below it hold the "<" elements)
     uint32_t ckey[2][6];           // child boxes (A, B) as keys
     uint32_t ccen[2][6];           // child centroid ranges (A, B) as keys: the next level's step 1, gathered by big_scatter
@@ -1444,7 +1446,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         const uint32_t row_next = (row + 1u) % 3u, next = (parity ^ 1u) | (row_next << 8);
         const uint32_t nb = hc.cnt[row][CLS_BIG].v;
         if (nb) {                                       // top of the tree: nodes too large for one workgroup (chunks of kChunk);
-                                                        // its own stream: these 9 launches overlap the level's block / wave / tiny kernels
+                                                        // its own stream: these 8 launches overlap the level's wave / group / thread kernels
             const uint32_t nc = n_tris / kChunk + nb;   // bound on sum(ceil(n_j / kChunk)); the real count lives in ctrl->n_chunks
             if (nb > big_cap || nc > chunk_cap) { cleanup(); mipt_internal_set_error("mipt_bvh_build_device: internal capacity"); return MIPT_ERR_BVH; }
             const dim3 gb((nb + 63) / 64), tb(64);
