@@ -1347,6 +1347,20 @@ int fail(int code, const char *what, hipError_t e) {
 // The build proper: triangles already in HBM (`d_tris`, original order), results stay in HBM -- the node array in the reference's
 // order and the permutation BVH::build applied to the triangles (reordered[t] = original[tri_order[t]]).  Both are hipMalloc'ed here
 // and owned by the caller.  Used by mipt_bvh_build_device (below) and by the device-resident scene setup (scene_device.hip).
+// The runtime resolves a kernel the first time it is launched (~60 us each, 25 kernels: the first build of a process took 1.5-2 ms
+// longer than the next).  A caller that is waiting for something else anyway (scene_device.hip: the upload) does it up front.
+void mipt::bvh_builder_resolve_kernels() {
+    const void *k[] = {(const void *)make_proxies, (const void *)init_root, (const void *)level_mark, (const void *)big_setup, (const void *)big_bin, (const void *)big_choose,
+                       (const void *)big_count2, (const void *)big_scan, (const void *)big_fill, (const void *)big_scatter, (const void *)big_finish,
+                       (const void *)build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>, (const void *)build_level_wave<128u, kWaveM, 8, 4>,
+                       (const void *)build_level_wave<kWaveS, 128u, 8, 6>, (const void *)build_level_wave<32u, kWaveS, 8, 8>, (const void *)build_level_group<32, 16u, 32u>,
+                       (const void *)build_level_group<16, kTiny, 16u>, (const void *)build_level_tiny, (const void *)build_subtree_tiny, (const void *)sizes_level,
+                       (const void *)sizes_run, (const void *)bases_level, (const void *)bases_run, (const void *)extract_order};
+    hipFuncAttributes a;
+    for (const void *f : k) (void)hipFuncGetAttributes(&a, f);
+    (void)hipGetLastError();
+}
+
 int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int device_id, ResidentBvh *res) {
     if (!d_tris || !res || n_tris == 0) { mipt_internal_set_error("mipt_bvh_build_device: bad argument (empty scene: the reference panics)"); return MIPT_ERR_INVALID_ARG; }
     *res = ResidentBvh{};

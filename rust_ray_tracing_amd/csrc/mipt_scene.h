@@ -68,5 +68,6 @@ struct ResidentBvh {
     double build_ms = 0.0;                // HIP events around the build kernels
 };
 int bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int device_id, ResidentBvh *out);
+void bvh_builder_resolve_kernels();         // optional: what the first launch of each builder kernel would pay, up front (call with the device set)
 
 } // namespace mipt

@@ -408,8 +408,10 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     // ---- 1. the one host -> device copy ----
     S_HIP(hipMalloc((void **)&d_tris, (size_t)n_tris * sizeof(MiptTriangle)));
     {
+        std::thread warm([device_id]() { if (hipSetDevice(device_id) == hipSuccess) mipt::bvh_builder_resolve_kernels(); });   // beside the copies
         int rc = up_ring.copy(d_tris, desc->tris, (size_t)n_tris * sizeof(MiptTriangle));
         if (rc == MIPT_OK) rc = up_ring.finish();
+        warm.join();
         up_ring.pause();                                      // back for the textures, after the build
         if (rc) { cleanup(); return rc; }
     }
