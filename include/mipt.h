@@ -257,7 +257,8 @@ typedef struct {
 } MiptMultiStats;
 
 /* device_ids: n_devices HIP device ordinals (NULL = 0..n_devices-1; n_devices 0 = every visible device).  The scene crosses PCIe
- * ONCE, to device_ids[0]; the other replicas are device-to-device copies over xGMI.  Creates the communicators. */
+ * ONCE, to device_ids[0]; the other replicas are device-to-device copies over xGMI, all queued before the first is waited for
+ * (pulls from one GPU use one link per destination).  Creates the communicators. */
 MIPT_API int  mipt_multi_create(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);
 /* Same from the triangles alone (mipt_scene_create_from_triangles on device_ids[0], then the xGMI replicas). */
 MIPT_API int  mipt_multi_create_from_triangles(const MiptSceneDesc *desc, const int *device_ids, int n_devices, MiptMulti **out);

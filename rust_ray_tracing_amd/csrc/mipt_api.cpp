@@ -219,9 +219,10 @@ int mipt::scene_finish_workspace(MiptScene *s) {
 
 // Replica by device-to-device copy.  hipMemcpyPeer needs no peer mapping; with one enabled (tried, failure ignored) the copy engines
 // move the data directly over the xGMI link between the two GPUs instead of staging it.
-int mipt::scene_clone_to(const MiptScene *src, int device, MiptScene **out) {
+// Two phases, so that several replicas are in flight at once (mipt::scene_clone_many): `clone_issue` allocates on the destination and
+// queues the copies on ITS null stream, `clone_finish` waits for them.  Seven pulls from device 0 use seven different xGMI links.
+static int clone_issue(const MiptScene *src, int device, MiptScene **out) {
     *out = nullptr;
-    const double t0 = now_ms();
     HIP_TRY(hipSetDevice(device));
     if (device != src->device) {
         int can = 0;
@@ -249,14 +250,20 @@ int mipt::scene_clone_to(const MiptScene *src, int device, MiptScene **out) {
         if (!p.from) continue;
         hipError_t e = hipMalloc(p.dst, p.alloc ? p.alloc : 16);
         if (e == hipSuccess && p.copy) e = hipMemcpyPeerAsync(*p.dst, device, p.from, src->device, p.copy, nullptr);
-        if (e != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "replica copy %d -> %d: %s", src->device, device, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(nullptr); free_scene(s); return fail(MIPT_ERR_HIP, "replica copy %d -> %d: %s", src->device, device, hipGetErrorString(e)); }
     }
+    *out = s;
+    return MIPT_OK;
+}
+static int clone_finish(const MiptScene *src, MiptScene *s, double t0) {
+    const int device = s->device;
+    HIP_TRY(hipSetDevice(device));
     {
         const hipError_t e = hipStreamSynchronize(nullptr);
-        if (e != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "replica copy %d -> %d: %s", src->device, device, hipGetErrorString(e)); }
+        if (e != hipSuccess) return fail(MIPT_ERR_HIP, "replica copy %d -> %d: %s", src->device, device, hipGetErrorString(e));
     }
-    const int rc = scene_finish_workspace(s);
-    if (rc) { free_scene(s); return rc; }
+    const int rc = mipt::scene_finish_workspace(s);
+    if (rc) return rc;
     const size_t pairs_bytes = src->dev.tri_off_bytes;
     s->dev.pairs = (const float4 *)s->d_geom;
     s->dev.tri_pos = (const float4 *)((const char *)s->d_geom + pairs_bytes);
@@ -266,7 +273,30 @@ int mipt::scene_clone_to(const MiptScene *src, int device, MiptScene **out) {
     s->dev.texels = (const uint32_t *)s->d_texels;
     s->info.replica_of_device = (uint32_t)src->device + 1u;
     s->info.upload_ms = now_ms() - t0; s->info.build_ms = 0.0; s->info.layout_ms = 0.0; s->info.total_ms = s->info.upload_ms;
-    *out = s;
+    return MIPT_OK;
+}
+int mipt::scene_clone_to(const MiptScene *src, int device, MiptScene **out) {
+    const double t0 = now_ms();
+    int rc = clone_issue(src, device, out);
+    if (rc == MIPT_OK && (rc = clone_finish(src, *out, t0))) { free_scene(*out); *out = nullptr; }
+    return rc;
+}
+// outs[1 .. n) = replicas of `src` (= outs[0]) on device_ids[1 .. n), all copies queued before the first is waited for; a replica's
+// upload_ms runs from the common start to ITS completion.  On failure every replica made here is freed and outs[i >= 1] are null.
+int mipt::scene_clone_many(const MiptScene *src, const int *device_ids, int n_dev, MiptScene **outs) {
+    const double t0 = now_ms();
+    int rc = MIPT_OK, fail_dev = -1;
+    for (int i = 1; i < n_dev && rc == MIPT_OK; i++) if ((rc = clone_issue(src, device_ids[i], &outs[i]))) fail_dev = device_ids[i];
+    for (int i = 1; i < n_dev; i++) {
+        if (!outs[i]) continue;
+        const int r = clone_finish(src, outs[i], t0);            // also when an earlier one failed: the copies are in flight
+        if (r && rc == MIPT_OK) { rc = r; fail_dev = device_ids[i]; }
+    }
+    if (rc) {
+        const std::string msg = g_err;
+        for (int i = 1; i < n_dev; i++) { free_scene(outs[i]); outs[i] = nullptr; }
+        return fail(rc, "replica on device %d: %s", fail_dev, msg.c_str());
+    }
     return MIPT_OK;
 }
 
@@ -499,14 +529,12 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     s->info.geometry_bytes = (uint64_t)pairs_bytes + pos_bytes + s->attr_bytes;
     s->info.layout_ms = t_layout - t_begin; s->info.upload_ms = t_up - t_layout; s->info.total_ms = t_up - t_begin;
     outs[0] = s;
-    for (int i = 1; i < n_dev; i++) {
-        if ((rc = mipt::scene_clone_to(s, device_ids[i], &outs[i]))) {
-            const std::string msg = g_err;
-            for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
-            return fail(rc, "replica on device %d: %s", device_ids[i], msg.c_str());
-        }
+    if ((rc = mipt::scene_clone_many(s, device_ids, n_dev, outs))) {
+        const std::string msg = g_err;
+        free_scene(outs[0]); outs[0] = nullptr;
+        g_err = msg;
     }
-    return MIPT_OK;
+    return rc;
 }
 
 static int scene_create_impl(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
@@ -527,13 +555,10 @@ static int scene_create_many_from_triangles(const MiptSceneDesc *desc, const int
     if (!desc || !outs || !device_ids || n_dev < 1) return fail(MIPT_ERR_INVALID_ARG, "mipt_multi_create_from_triangles: null argument");
     for (int i = 0; i < n_dev; i++) outs[i] = nullptr;
     int rc = mipt::scene_create_from_triangles(desc, device_ids[0], &outs[0]);
-    for (int i = 1; i < n_dev && rc == MIPT_OK; i++) {
-        rc = mipt::scene_clone_to(outs[0], device_ids[i], &outs[i]);
-        if (rc) { const std::string msg = g_err; fail(rc, "replica on device %d: %s", device_ids[i], msg.c_str()); }
-    }
+    if (rc == MIPT_OK) rc = mipt::scene_clone_many(outs[0], device_ids, n_dev, outs);
     if (rc) {
         const std::string msg = g_err;
-        for (int j = 0; j < n_dev; j++) { free_scene(outs[j]); outs[j] = nullptr; }
+        free_scene(outs[0]); outs[0] = nullptr;
         g_err = msg;
     }
     return rc;

@@ -43,6 +43,9 @@ int scene_finish_workspace(MiptScene *s);
 // A replica of `src` in the memory of `device` by device-to-device copies (xGMI between GPUs of a node; a plain copy on the same
 // device), queued on `stream` of... the current device is left at `device`.  No host staging.
 int scene_clone_to(const MiptScene *src, int device, MiptScene **out);
+// outs[1 .. n_dev) = replicas of `src` on device_ids[1 .. n_dev), every copy queued before the first is waited for (seven pulls from
+// one GPU run on seven xGMI links at once); all-or-nothing.
+int scene_clone_many(const MiptScene *src, const int *device_ids, int n_dev, MiptScene **outs);
 
 // Host tables of a scene's materials and textures (mipt_api.cpp): the 64-B CPU-shading record, the 128-B record of the wgpu
 // material model and the texel pool.
