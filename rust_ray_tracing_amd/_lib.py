@@ -220,7 +220,7 @@ def load_multitest() -> C.CDLL:
 DIAG_LIB_PATH = os.path.join(_HERE, "libmipt_diag.so")
 DIAG_EXPORTS = ["mipt_debug_eval", "mipt_debug_eval_range", "mipt_diag_last_error",
                 "mipt_internal_pair_order", "mipt_internal_pair_order_top", "mipt_internal_tri_slots",
-                "mipt_diag_scene_sizes", "mipt_diag_scene_read", "mipt_diag_scene_hash", "mipt_diag_write_obj"]
+                "mipt_diag_scene_sizes", "mipt_diag_scene_read", "mipt_diag_scene_hash", "mipt_diag_write_obj", "mipt_diag_host_layout", "mipt_diag_hash_words"]
 _diag = None
 
 
@@ -256,6 +256,10 @@ def load_diag() -> C.CDLL:
     lib.mipt_diag_scene_hash.restype = C.c_int
     lib.mipt_diag_write_obj.argtypes = [C.c_char_p, vp, C.c_uint64, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]
     lib.mipt_diag_write_obj.restype = C.c_int
+    lib.mipt_diag_host_layout.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64 * 2), C.POINTER(C.c_uint32 * 4)]
+    lib.mipt_diag_host_layout.restype = C.c_int
+    lib.mipt_diag_hash_words.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.mipt_diag_hash_words.restype = C.c_int
     _diag = lib
     return lib
 

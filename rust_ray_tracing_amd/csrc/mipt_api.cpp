@@ -93,30 +93,7 @@ int ensure(void **p, size_t *have, size_t want_bytes) {
     return MIPT_OK;
 }
 
-// Host-side layout helpers.  The device layout of a 10 M-triangle scene is ~2 GB written once: std::vector would zero (touch) every
-// page on one thread before the fill loop writes it again, so the big arrays are malloc'ed (filled completely) or calloc'ed (pages
-// arrive zeroed from the kernel when a worker first touches them), and the fill loops run on up to 16 threads.
-template <class T> struct HostBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    HostBuf() = default;
-    HostBuf(const HostBuf &) = delete;
-    HostBuf &operator=(const HostBuf &) = delete;
-    ~HostBuf() { free(p); }
-    bool alloc(size_t count, bool zeroed) {
-        free(p);
-        n = count;
-        p = (T *)(zeroed ? calloc(count ? count : 1, sizeof(T)) : malloc((count ? count : 1) * sizeof(T)));
-        return p != nullptr;
-    }
-    void swap(HostBuf &o) { T *tp = p; p = o.p; o.p = tp; size_t tn = n; n = o.n; o.n = tn; }
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
-    T *data() { return p; }
-    size_t size() const { return n; }
-};
-template <class T>
-int upload(void **dst, const HostBuf<T> &src, size_t min_bytes = 16) { return upload(dst, src.p, src.n, min_bytes); }
+// host loops over the caller's arrays (the material-id check) on up to 16 threads
 template <class F> void parallel_for(size_t n, F body) {                 // body(begin, end) on disjoint ranges; results must not depend on the split
     unsigned t = std::thread::hardware_concurrency();
     if (t > 16u) t = 16u;
@@ -338,27 +315,21 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     if (n_pairs > mipt::kMaxPairs) return fail(MIPT_ERR_SCENE_LIMIT, "%u node pairs exceed the 2^24 device-format limit", n_pairs);
     const double t_begin = now_ms();
 
-    // ---- validate and re-base the BVH: pair[k] = {nodes[2k+1], nodes[2k+2]} ----
-    uint32_t max_leaf = 0;
-    uint32_t tiny_axes = 0;
+    // ---- validate the BVH on the host, before anything touches the device (the layout kernels index with these fields) ----
     std::vector<uint8_t> pair_seen(n_pairs, 0), tri_seen(desc->n_tris, 0);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const MiptNode &n = desc->nodes[i];
-        {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused); axes on which some
-            // plane coordinate is tiny but not 0 are flagged, and a ray starting at exactly 0 on such an axis divides the IEEE way
-            // (pt_kernel.hip ray_safe)
-            const float lim = 1.0995116e12f, tiny = 1.3234890e-23f /* 2^-76 */;
+        {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused).  (Axes with tiny
+            // non-zero plane coordinates and the largest leaf are found by the device's own pass over the nodes, scene_device.hip.)
+            const float lim = 1.0995116e12f;
             const float *b = &n.bounds_min.x, *c = &n.bounds_max.x;
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 3; k++)
                 if (!(fabsf(b[k]) <= lim) || !(fabsf(c[k]) <= lim))
                     return fail(MIPT_ERR_SCENE_LIMIT, "node %u has a non-finite bound or one beyond 2^40", i);
-                if ((b[k] != 0.0f && fabsf(b[k]) < tiny) || (c[k] != 0.0f && fabsf(c[k]) < tiny)) tiny_axes |= 1u << k;
-            }
         }
         if (n.num_tris > 0) {
             if ((uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris)
                 return fail(MIPT_ERR_BVH, "leaf node %u covers triangles [%u, %u+%u) beyond n_tris=%u", i, n.first_tri_or_child, n.first_tri_or_child, n.num_tris, desc->n_tris);
-            if (n.num_tris > max_leaf) max_leaf = n.num_tris;
             // leaves partition the triangle array (bvh.rs:99-115 splits a node's range in place); the device stream re-packs
             // leaf by leaf, so a triangle in two leaves cannot be represented
             for (uint32_t t = n.first_tri_or_child; t < n.first_tri_or_child + n.num_tris; t++) {
@@ -377,157 +348,34 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     }
     for (uint32_t k = 0; k < n_pairs; k++)
         if (!pair_seen[k]) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * k + 1, 2 * k + 2);
-    // ---- slots of the intersection stream (mipt::tri_slots, bvh_build.cpp): where triangle i's 64-B record sits ----
-    std::vector<uint32_t> slot_of_tri(desc->n_tris);
-    uint32_t n_slots = 0;
-    if (mipt::tri_slots(desc->nodes, desc->n_nodes, desc->n_tris, slot_of_tri.data(), &n_slots) != MIPT_OK)
-        return fail(MIPT_ERR_BVH, "triangle slots: malformed BVH");
-    HostBuf<float4> pairs;                                                  // (+4: room for the pad record below)
-    if (!pairs.alloc((size_t)n_pairs * 4 + 4, false)) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
-    pairs.n = (size_t)n_pairs * 4;
-    for (int q = 0; q < 4; q++) pairs[(size_t)n_pairs * 4 + q] = make_float4(0, 0, 0, 0);
-    parallel_for(n_pairs, [&](size_t kb, size_t ke) {
-        for (size_t k = kb; k < ke; k++) {
-            for (uint32_t w = 0; w < 2; w++) {
-                const MiptNode &n = desc->nodes[2 * k + 1 + w];
-                const uint32_t a = n.num_tris > 0 ? slot_of_tri[n.first_tri_or_child] : (n.first_tri_or_child - 1u) / 2u;
-                float4 lo, hi;
-                lo.x = n.bounds_min.x; lo.y = n.bounds_min.y; lo.z = n.bounds_min.z; memcpy(&lo.w, &a, 4);
-                hi.x = n.bounds_max.x; hi.y = n.bounds_max.y; hi.z = n.bounds_max.z; memcpy(&hi.w, &n.num_tris, 4);
-                pairs[k * 4 + w * 2 + 0] = lo;
-                pairs[k * 4 + w * 2 + 1] = hi;
-            }
-        }
-    });
-    // ---- order of the pair records in HBM (mipt::pair_order, bvh_build.cpp): the tree top breadth-first, below it every
-    // pair in one 128-B line with the child pair of its larger inner child.  Topology, visit order and results are untouched; only
-    // `a` of the inner children is renumbered.
-    std::vector<uint32_t> new_of(n_pairs);                                  // reference pair index -> record index in HBM
-    for (uint32_t k = 0; k < n_pairs; k++) new_of[k] = k;
-    if (n_pairs > 0) {
-        std::vector<uint32_t> order(2 * (size_t)n_pairs + 2);               // record index -> reference pair index (0xffffffff = pad; at most one pad per level)
-        uint32_t n_records = 0;
-        {
-            const uint32_t cap = order.size() < (size_t)mipt::kMaxPairs ? (uint32_t)order.size() : mipt::kMaxPairs;
-            const int rc = mipt::pair_order(desc->nodes, desc->n_nodes, order.data(), cap, &n_records);   // bvh_build.cpp
-            if (rc != MIPT_OK) return fail(rc, "pair records (with line padding) exceed the 2^24 device-format limit or the order buffer");
-        }
-        order.resize(n_records);
-        auto child_pair = [&](uint32_t k, uint32_t w, uint32_t *out) -> bool {
-            const MiptNode &n = desc->nodes[2 * k + 1 + w];
-            if (n.num_tris != 0u) return false;
-            *out = (n.first_tri_or_child - 1u) / 2u;
-            return true;
-        };
-        parallel_for(order.size(), [&](size_t jb, size_t je) {
-            for (size_t j = jb; j < je; j++) if (order[j] != 0xffffffffu) new_of[order[j]] = (uint32_t)j;      // every pair appears once: disjoint writes
-        });
-        HostBuf<float4> re;                                                 // pad records stay zero (calloc)
-        if (!re.alloc(order.size() * 4 + 4, true)) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
-        re.n = order.size() * 4;
-        parallel_for(order.size(), [&](size_t jb, size_t je) {
-            for (size_t j = jb; j < je; j++) {
-                if (order[j] == 0xffffffffu) continue;
-                for (int q = 0; q < 4; q++) re[j * 4 + q] = pairs[(size_t)order[j] * 4 + q];
-                for (uint32_t w = 0; w < 2; w++) {
-                    uint32_t c;
-                    if (child_pair(order[j], w, &c)) memcpy(&re[j * 4 + w * 2].w, &new_of[c], 4);
-                }
-            }
-        });
-        pairs.swap(re);
-    }
-    if ((pairs.size() / 4) & 1u) pairs.n += 4;                             // one zero pad record (allocated above): the triangle stream behind it starts on a 128-B line
-    const uint32_t n_pair_records = (uint32_t)(pairs.size() / 4);
-    // ---- triangles: 64-B-strided intersection stream + 64-B shading stream ----
-    if (n_slots > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, "%u triangle slots exceed the 2^25 device-format limit", n_slots);
-    HostBuf<float4> tri_pos, tri_attr;                                      // tri_pos: +1 for the kernel's unconditional 4th float4 load; unused slots / words stay zero
-    if (!tri_pos.alloc((size_t)n_slots * mipt::kTriPosStride / 16 + 1, true) || !tri_attr.alloc((size_t)desc->n_tris * 4, false))
-        return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
-    std::atomic<uint32_t> bad_tri{UINT32_MAX};
-    parallel_for(desc->n_tris, [&](size_t ib, size_t ie) {
-        for (size_t ii = ib; ii < ie; ii++) {
-            const uint32_t i = (uint32_t)ii;
-            const MiptTriangle &t = desc->tris[i];
-            if (t.material_id >= desc->n_materials) {                      // reported below: the lowest such triangle, as a sequential scan would
-                uint32_t cur = bad_tri.load();
-                while (i < cur && !bad_tri.compare_exchange_weak(cur, i)) {}
-                continue;
-            }
-            const MiptVec3 v0 = t.vertices[0].position, v1 = t.vertices[1].position, v2 = t.vertices[2].position;
-            // edge_1 = v_2 - v_1, edge_2 = v_3 - v_1 (ray.rs:24-25): one rounded f32 subtraction each,
-            // the same value the reference recomputes per test (-ffp-contract=off; no fusing possible here).
-            const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
-            const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
-            const size_t q = (size_t)slot_of_tri[i] * (mipt::kTriPosStride / 16);
-            float idf;
-            memcpy(&idf, &i, 4);
-            tri_pos[q + 0] = make_float4(v0.x, v0.y, v0.z, e1x);
-            tri_pos[q + 1] = make_float4(e1y, e1z, e2x, e2y);
-            tri_pos[q + 2] = make_float4(e2z, idf, 0.0f, 0.0f);
-            const MiptVec3 n0 = t.vertices[0].normal, n1 = t.vertices[1].normal, n2 = t.vertices[2].normal;
-            float mid;
-            memcpy(&mid, &t.material_id, 4);
-            tri_attr[(size_t)i * 4 + 0] = make_float4(n0.x, n0.y, n0.z, n1.x);
-            tri_attr[(size_t)i * 4 + 1] = make_float4(n1.y, n1.z, n2.x, n2.y);
-            tri_attr[(size_t)i * 4 + 2] = make_float4(n2.z, t.vertices[0].tex_coord_x, t.vertices[0].tex_coord_y, t.vertices[1].tex_coord_x);
-            tri_attr[(size_t)i * 4 + 3] = make_float4(t.vertices[1].tex_coord_y, t.vertices[2].tex_coord_x, t.vertices[2].tex_coord_y, mid);
-        }
-    });
-    if (bad_tri.load() != UINT32_MAX)
-        return fail(MIPT_ERR_INVALID_ARG, "triangle %u has material_id %u >= n_materials %u", bad_tri.load(), desc->tris[bad_tri.load()].material_id, desc->n_materials);
-    // ---- materials / textures ----
-    mipt::MaterialTables tables;
+    // the reference indexes `materials[material_id]` and would panic; the lowest offender is reported, as a sequential scan would
     {
-        const int rc = mipt::build_material_tables(desc, &tables);
-        if (rc) return rc;
+        std::atomic<uint32_t> bad_tri{UINT32_MAX};
+        parallel_for(desc->n_tris, [&](size_t ib, size_t ie) {
+            for (size_t ii = ib; ii < ie; ii++) {
+                if (desc->tris[ii].material_id < desc->n_materials) continue;
+                uint32_t cur = bad_tri.load();
+                while ((uint32_t)ii < cur && !bad_tri.compare_exchange_weak(cur, (uint32_t)ii)) {}
+            }
+        });
+        if (bad_tri.load() != UINT32_MAX)
+            return fail(MIPT_ERR_INVALID_ARG, "triangle %u has material_id %u >= n_materials %u", bad_tri.load(), desc->tris[bad_tri.load()].material_id, desc->n_materials);
     }
-
     if (desc->nodes[0].num_tris == 0 && desc->nodes[0].first_tri_or_child != 1u)
         return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)");
-    // pairs and tri_pos share one allocation (one buffer descriptor, 32-bit offsets in the kernel)
-    const size_t pairs_bytes = pairs.size() * sizeof(float4), pos_bytes = tri_pos.size() * sizeof(float4);
-    if (pairs_bytes + pos_bytes >= 0xffffffffull) return fail(MIPT_ERR_SCENE_LIMIT, "BVH + triangle stream exceed 4 GiB");
-
-    const double t_layout = now_ms();
-    // ---- device(s): the scene crosses PCIe once, to device_ids[0]; further replicas are device-to-device copies ----
+    // ---- device(s).  Triangles and nodes cross PCIe once, to device_ids[0], and the layout -- triangle slots, the order of the pair
+    // records, both triangle streams -- is produced there by the kernels mipt_scene_create_from_triangles uses after its build
+    // (scene_device.hip); further replicas are device-to-device copies.  (Rounds 1-3 laid the scene out on host threads: 0.55 s for
+    // 10 M triangles; that code now lives in libmipt_diag.so as the byte-for-byte reference of the kernels, tests/cpp/host_layout.cpp.)
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     for (int i = 0; i < n_dev; i++)
         if (device_ids[i] < 0 || device_ids[i] >= ndev) return fail(MIPT_ERR_HIP, "HIP device %d not available (%d visible)", device_ids[i], ndev);
-    HIP_TRY(hipSetDevice(device_ids[0]));
-    MiptScene *s = new (std::nothrow) MiptScene();
-    if (!s) return fail(MIPT_ERR_INVALID_ARG, "out of host memory");
-    s->device = device_ids[0];
-    s->max_leaf = max_leaf;
-    s->n_tris = desc->n_tris;
-    int rc;
-    {
-        s->geom_alloc = pairs_bytes + pos_bytes + 64;
-        hipError_t e1 = hipMalloc(&s->d_geom, s->geom_alloc);
-        if (e1 == hipSuccess && pairs_bytes) e1 = hipMemcpy(s->d_geom, pairs.data(), pairs_bytes, hipMemcpyHostToDevice);
-        if (e1 == hipSuccess) e1 = hipMemcpy((char *)s->d_geom + pairs_bytes, tri_pos.data(), pos_bytes, hipMemcpyHostToDevice);
-        if (e1 != hipSuccess) { free_scene(s); return fail(MIPT_ERR_HIP, "geometry upload: %s", hipGetErrorString(e1)); }
-    }
-    s->attr_bytes = tri_attr.size() * sizeof(float4);
-    if ((rc = upload(&s->d_tri_attr, tri_attr)) || (rc = mipt::upload_material_tables(s, tables)) || (rc = mipt::scene_finish_workspace(s))) {
-        free_scene(s);
-        return rc;
-    }
-    s->dev.pairs = (const float4 *)s->d_geom;
-    s->dev.tri_pos = (const float4 *)((const char *)s->d_geom + pairs_bytes);
-    s->dev.tri_off_bytes = (uint32_t)pairs_bytes;
-    s->dev.geom_bytes = (uint32_t)(pairs_bytes + pos_bytes);
-    s->dev.tiny_axes = tiny_axes;
-    s->dev.tri_attr = (const float4 *)s->d_tri_attr;
-    s->dev.n_pairs = n_pair_records; s->dev.n_tris = desc->n_tris; s->dev.n_mats = desc->n_materials; s->dev.n_texs = desc->n_textures;
-    // root (nodes[0]): a leaf when BVH::build refused to split (bvh.rs:94), else its children are pair 0
-    s->dev.root_a = desc->nodes[0].num_tris > 0 ? slot_of_tri[desc->nodes[0].first_tri_or_child] : 0u;
-    s->dev.root_n = desc->nodes[0].num_tris;
-    const double t_up = now_ms();
-    s->info.n_tris = desc->n_tris; s->info.n_nodes = desc->n_nodes; s->info.n_pair_records = n_pair_records; s->info.max_leaf = max_leaf;
-    s->info.geometry_bytes = (uint64_t)pairs_bytes + pos_bytes + s->attr_bytes;
-    s->info.layout_ms = t_layout - t_begin; s->info.upload_ms = t_up - t_layout; s->info.total_ms = t_up - t_begin;
+    MiptScene *s = nullptr;
+    int rc = mipt::scene_create_from_nodes(desc, device_ids[0], &s);
+    if (rc) return rc;
+    s->info.layout_ms += now_ms() - t_begin - s->info.total_ms;             // + the host checks above
+    s->info.total_ms = now_ms() - t_begin;
     outs[0] = s;
     if ((rc = mipt::scene_clone_many(s, device_ids, n_dev, outs))) {
         const std::string msg = g_err;

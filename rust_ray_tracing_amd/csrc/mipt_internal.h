@@ -19,6 +19,8 @@ int tri_slots(const MiptNode *nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t
 // ---- scene_device.hip ----
 // mipt_scene_create_from_triangles without the exception fence.
 int scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out);
+// the same with the caller's node array (ALREADY validated: mipt_scene_create's host checks) instead of a build; triangles in the tree's order
+int scene_create_from_nodes(const MiptSceneDesc *desc, int device_id, MiptScene **out);
 
 // ---- mipt_api.cpp, used by mipt_multi.cpp ----
 // One scene on device_ids[0] -- from host-built nodes (one host-side layout build, one upload) or, with from_triangles, built on that

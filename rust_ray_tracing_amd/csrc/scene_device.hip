@@ -282,7 +282,7 @@ __global__ void write_pairs(const MiptNode *nodes, const uint32_t *order, uint32
 __global__ void write_tris(const MiptTriangle *tris, const uint32_t *tri_order, uint32_t n_tris, uint32_t n_materials, const uint32_t *slot,
                            float4 *tri_pos, float4 *tri_attr, Ctl *ctl) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tris; t += gridDim.x * blockDim.x) {
-        const float4 *src = reinterpret_cast<const float4 *>(tris + tri_order[t]);
+        const float4 *src = reinterpret_cast<const float4 *>(tris + (tri_order ? tri_order[t] : t));   // no permutation: the caller's triangles are in the tree's order already
         const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6];
         // Vertex = {position.xyz, u, normal.xyz, v}: a0 a1 | a2 a3 | a4 a5; a6.x = material_id
         const uint32_t mat = __float_as_uint(a6.x);
@@ -375,11 +375,14 @@ class StagedUploader {
 
 } // namespace
 
-int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
+// Both ways in end here.  `host_nodes`: the caller's node array (validated by mipt_scene_create, mipt_api.cpp) is uploaded beside the
+// triangles, which are in the tree's order already; else BVH::build runs on the GPU.  The layout kernels are the same.
+static int create_on_device(const MiptSceneDesc *desc, int device_id, bool host_nodes, MiptScene **out) {
     if (!desc || !out) return fail(MIPT_ERR_INVALID_ARG, "mipt_scene_create_from_triangles: null argument");
     *out = nullptr;
     if (!desc->tris || desc->n_tris == 0) return fail(MIPT_ERR_INVALID_ARG, "scene has no triangles (the reference panics in BVH::build)");
     if (desc->n_tris > mipt::kMaxTris) return fail(MIPT_ERR_SCENE_LIMIT, std::to_string(desc->n_tris) + " triangles exceed the 2^25 device-format limit");
+    if (host_nodes && (!desc->nodes || (desc->n_nodes & 1u) == 0u)) return fail(MIPT_ERR_BVH, "scene has no BVH nodes, or an even number of them");
     const double t_begin = now_ms();
     mipt::MaterialTables tables;
     { const int rc = mipt::build_material_tables(desc, &tables, false); if (rc) return rc; }     // the textures are staged below, not gathered on the host
@@ -407,17 +410,21 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     S_HIP(hipSetDevice(device_id));
     // ---- 1. the one host -> device copy ----
     S_HIP(hipMalloc((void **)&d_tris, (size_t)n_tris * sizeof(MiptTriangle)));
+    if (host_nodes) S_HIP(hipMalloc((void **)&bvh.d_nodes, (size_t)desc->n_nodes * sizeof(MiptNode)));
     {
-        std::thread warm([device_id]() { if (hipSetDevice(device_id) == hipSuccess) mipt::bvh_builder_resolve_kernels(); });   // beside the copies
+        std::thread warm;
+        if (!host_nodes) warm = std::thread([device_id]() { if (hipSetDevice(device_id) == hipSuccess) mipt::bvh_builder_resolve_kernels(); });   // beside the copies
         int rc = up_ring.copy(d_tris, desc->tris, (size_t)n_tris * sizeof(MiptTriangle));
+        if (rc == MIPT_OK && host_nodes) rc = up_ring.copy(bvh.d_nodes, desc->nodes, (size_t)desc->n_nodes * sizeof(MiptNode));
         if (rc == MIPT_OK) rc = up_ring.finish();
-        warm.join();
+        if (warm.joinable()) warm.join();
         up_ring.pause();                                      // back for the textures, after the build
         if (rc) { cleanup(); return rc; }
     }
     const double t_up = now_ms();
-    // ---- 2. BVH::build in HBM ----
-    { const int rc = mipt::bvh_build_resident(d_tris, n_tris, device_id, &bvh); if (rc) { cleanup(); return rc; } }
+    // ---- 2. BVH::build in HBM (or the caller's tree) ----
+    if (host_nodes) bvh.n_nodes = desc->n_nodes;
+    else { const int rc = mipt::bvh_build_resident(d_tris, n_tris, device_id, &bvh); if (rc) { cleanup(); return rc; } }
     const double t_build = now_ms();
     const uint32_t n_nodes = bvh.n_nodes;
     if ((n_nodes & 1u) == 0u) { cleanup(); return fail(MIPT_ERR_BVH, "device builder returned an even node count"); }
@@ -499,7 +506,8 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     S_HIP(hipStreamSynchronize(st));
     if (hctl.bad_tri != 0xffffffffu) {
         cleanup();
-        return fail(MIPT_ERR_INVALID_ARG, "a triangle has material_id >= n_materials " + std::to_string(desc->n_materials) + " (position " + std::to_string(hctl.bad_tri) + " of the BVH order)");
+        return fail(MIPT_ERR_INVALID_ARG, host_nodes ? "triangle " + std::to_string(hctl.bad_tri) + " has material_id >= n_materials " + std::to_string(desc->n_materials)
+                                                     : "a triangle has material_id >= n_materials " + std::to_string(desc->n_materials) + " (position " + std::to_string(hctl.bad_tri) + " of the BVH order)");
     }
     if (root.num_tris > 0u) S_HIP(hipMemcpy(&root_slot, slot + root.first_tri_or_child, 4, hipMemcpyDeviceToHost));
     else if (root.first_tri_or_child != 1u) { cleanup(); return fail(MIPT_ERR_BVH, "root's children must be nodes 1 and 2 (bvh.rs:121)"); }
@@ -508,9 +516,12 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     const double t_layout = now_ms();
 
     s->max_leaf = hctl.max_leaf;
-    s->d_nodes = bvh.d_nodes; bvh.d_nodes = nullptr;                // kept for mipt_scene_get_bvh
     s->n_nodes = n_nodes;
-    s->d_tri_order = bvh.d_tri_order; bvh.d_tri_order = nullptr;
+    if (host_nodes) { (void)hipFree(bvh.d_nodes); bvh.d_nodes = nullptr; }          // the caller has them
+    else {                                                                           // kept for mipt_scene_get_bvh
+        s->d_nodes = bvh.d_nodes; bvh.d_nodes = nullptr;
+        s->d_tri_order = bvh.d_tri_order; bvh.d_tri_order = nullptr;
+    }
     {   // materials + the texel pool; the textures go through the same pinned ring, straight from the caller's buffers
         int rc = mipt::upload_material_tables(s, tables);
         for (uint32_t i = 0; i < desc->n_textures && rc == MIPT_OK; i++)
@@ -532,15 +543,18 @@ int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, 
     const double t_end = now_ms();
     s->info.n_tris = n_tris; s->info.n_nodes = n_nodes; s->info.n_pair_records = n_records_padded; s->info.max_leaf = hctl.max_leaf;
     s->info.geometry_bytes = (uint64_t)pairs_bytes + pos_bytes + s->attr_bytes;
-    s->info.built_on_device = 1;
+    s->info.built_on_device = host_nodes ? 0u : 1u;
     s->info.upload_ms = (t_up - t_begin) + (t_end - t_layout);
-    s->info.build_ms = bvh.build_ms;
+    s->info.build_ms = host_nodes ? 0.0 : bvh.build_ms;
     s->info.layout_ms = t_layout - t_build;
     s->info.total_ms = t_end - t_begin;
     *out = s;
     s = nullptr;
     return MIPT_OK;
 }
+
+int mipt::scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out) { return create_on_device(desc, device_id, false, out); }
+int mipt::scene_create_from_nodes(const MiptSceneDesc *desc, int device_id, MiptScene **out) { return create_on_device(desc, device_id, true, out); }
 
 extern "C" int mipt_scene_create_from_triangles(const MiptSceneDesc *desc, int device_id, MiptScene **out) {
     try { return mipt::scene_create_from_triangles(desc, device_id, out); }

@@ -208,6 +208,31 @@ class Scene:  # scene.rs:12-19
         self._handle, self._handle_device = h, device_id
         return h
 
+    def host_layout(self):
+        """TEST INFRASTRUCTURE (libmipt_diag.so, tests/cpp/host_layout.cpp): the geometry buffers as rounds 1-3 laid them out on the
+        host from this Scene's triangles and nodes -- the byte-for-byte reference of the device layout kernels both entries now use.
+        Returns (geom bytes, attr bytes, dict(n_pair_records, max_leaf, root_a, root_n))."""
+        diag = L.load_diag()
+        d = self.desc()
+        sizes, info = (C.c_uint64 * 2)(), (C.c_uint32 * 4)()
+        rc = diag.mipt_diag_host_layout(C.byref(d), None, 0, None, 0, C.byref(sizes), C.byref(info))
+        if rc:
+            raise RuntimeError(f"mipt_diag_host_layout failed with status {rc}")
+        geom, attr = np.zeros(sizes[0], dtype=np.uint8), np.zeros(sizes[1], dtype=np.uint8)
+        rc = diag.mipt_diag_host_layout(C.byref(d), geom.ctypes.data, sizes[0], attr.ctypes.data, sizes[1], C.byref(sizes), C.byref(info))
+        if rc:
+            raise RuntimeError(f"mipt_diag_host_layout failed with status {rc}")
+        return geom, attr, dict(n_pair_records=int(info[0]), max_leaf=int(info[1]), root_a=int(info[2]), root_n=int(info[3]))
+
+    def host_layout_fingerprint(self):
+        """(hash of geom, hash of attr, bytes of geom, bytes of attr) of host_layout(), comparable with mipt_diag_scene_hash / _sizes."""
+        geom, attr, _ = self.host_layout()
+        diag = L.load_diag()
+        hg, ha = C.c_uint64(), C.c_uint64()
+        assert diag.mipt_diag_hash_words(geom.ctypes.data, geom.size // 4, C.byref(hg)) == 0
+        assert diag.mipt_diag_hash_words(attr.ctypes.data, attr.size // 4, C.byref(ha)) == 0
+        return int(hg.value), int(ha.value), int(geom.size), int(attr.size)
+
     def upload_from_triangles(self, device_id: int = 0, fetch_bvh: bool = False) -> C.c_void_p:
         """BVH::build + upload in ONE call, everything after the triangle copy on the GPU (mipt_scene_create_from_triangles): the
         scene's triangles go up in their current order, the tree is built and laid out in HBM.  With ``fetch_bvh`` the Scene is

@@ -3,9 +3,10 @@
 The triangle array crosses PCIe once; BVH::build (reference src/bvh.rs:13-161) and the whole device layout are produced by GPU
 kernels (csrc/bvh_build_device.hip, csrc/scene_device.hip).  Checked here:
   * the tree and the triangle order it reports are the host builder's (= the reference's), node for node;
-  * the device layout -- pair records | intersection stream, attribute stream -- is BYTE-identical to what mipt_scene_create's host
-    code lays out from the same tree (read back through libmipt_diag.so);
-  * frames and all counters equal the host-path scene's and the oracle's;
+  * the device layout -- pair records | intersection stream, attribute stream -- of BOTH entries (this one and mipt_scene_create with
+    the caller's nodes, which runs the same layout kernels) is BYTE-identical to the host restatement of the layout that rounds
+    1-3 shipped (tests/cpp/host_layout.cpp in libmipt_diag.so, through which the device buffers are read back too);
+  * frames and all counters equal the scene's made from the caller's nodes and the oracle's;
   * replicas made by device-to-device copy render the same frame; errors are status codes."""
 import ctypes as C
 
@@ -70,21 +71,25 @@ def _check_scene(rrt, orc, tris, mats, texs, cam, w=96, h=54, spp=2, depth=8, or
     host = rrt.Scene.from_arrays(tris, mats, texs)
     assert _same_nodes(dev.bvh_nodes, host.bvh_nodes)
     assert dev.tris.tobytes() == host.tris.tobytes()
-    # 2. the layout is what the host code builds from that tree
+    # 2. the layout -- of this entry and of mipt_scene_create given that tree -- is what the host restatement builds from it
     ref = rrt.Scene.from_arrays(dev.tris, mats, texs, build_bvh=False)
     ref.bvh_nodes = dev.bvh_nodes.copy()
     hr = ref.upload(0)
-    g1, a1, h1 = _layout(rrt, hd)
-    g2, a2, h2 = _layout(rrt, hr)
-    assert g1.size == g2.size and a1.size == a2.size
-    assert np.array_equal(a1, a2), "attribute stream differs"
-    if not np.array_equal(g1, g2):
-        bad = np.flatnonzero(g1 != g2)
-        raise AssertionError(f"geometry differs in {bad.size} bytes, first at {bad[0]} (record {bad[0] // 64}) of {g1.size}")
-    assert h1 == h2
+    g0, a0, i0 = ref.host_layout()
+    h0 = ref.host_layout_fingerprint()
+    for name, handle in (("from_triangles", hd), ("from_nodes", hr)):
+        g1, a1, h1 = _layout(rrt, handle)
+        assert g1.size == g0.size and a1.size == a0.size, name
+        assert np.array_equal(a1, a0), name + ": attribute stream differs"
+        if not np.array_equal(g1, g0):
+            bad = np.flatnonzero(g1 != g0)
+            raise AssertionError(f"{name}: geometry differs in {bad.size} bytes, first at {bad[0]} (record {bad[0] // 64}) of {g1.size}")
+        assert h1 == h0[:2], name
     ri, hi = ref.info(), dev.info()
+    assert ri["built_on_device"] == 0 and hi["built_on_device"] == 1
     for k in ("n_tris", "n_nodes", "n_pair_records", "max_leaf", "geometry_bytes"):
         assert ri[k] == hi[k], k
+    assert hi["n_pair_records"] == i0["n_pair_records"] and hi["max_leaf"] == i0["max_leaf"]
     # 3. frames and counters
     for s_ in (dev, ref):
         s_.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))

@@ -1,6 +1,7 @@
-"""GPU box, builder-run: soak of the device-resident scene setup (mipt_scene_create_from_triangles) on random soups --
-for every soup the tree equals the host builder's and the device layout built by the GPU kernels (csrc/scene_device.hip) is
-byte-identical (order-dependent 64-bit fingerprints of both buffers, libmipt_diag.so) to mipt_scene_create's host layout of that tree.
+"""GPU box, builder-run: soak of the device-resident scene setup on random soups -- for every soup the tree of
+mipt_scene_create_from_triangles equals the host builder's, and the device layout built by the GPU kernels (csrc/scene_device.hip),
+for that entry and for mipt_scene_create given the tree, is byte-identical (order-dependent 64-bit fingerprints of both buffers,
+libmipt_diag.so) to the host restatement's layout of that tree (tests/cpp/host_layout.cpp).
     python tests/tools/soak_scene_device.py [n_soups] [seed]"""
 import ctypes as C
 import os
@@ -47,7 +48,8 @@ for it in range(n_soups):
                  and np.array_equal(dev.bvh_nodes["bounds_max"], host.bvh_nodes["bounds_max"]) and dev.tris.tobytes() == host.tris.tobytes())
     ref = rrt.Scene.from_arrays(dev.tris, [rrt.material_default()], [], build_bvh=False)
     ref.bvh_nodes = dev.bvh_nodes.copy()
-    same_layout = fingerprint(hd) == fingerprint(ref.upload(0))
+    want = ref.host_layout_fingerprint()
+    same_layout = fingerprint(hd) == want and fingerprint(ref.upload(0)) == want
     total += n
     if not (same_tree and same_layout):
         bad += 1
