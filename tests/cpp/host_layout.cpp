@@ -52,7 +52,7 @@ int host_layout(const MiptSceneDesc *desc, uint8_t *geom_out, uint64_t geom_cap,
     const uint32_t n_pairs = (desc->n_nodes - 1u) / 2u;
     uint32_t max_leaf = 0;
     for (uint32_t i = 0; i < desc->n_nodes; i++) if (desc->nodes[i].num_tris > max_leaf) max_leaf = desc->nodes[i].num_tris;
-    // ---- slots of the intersection stream (mipt::tri_slots, bvh_build.cpp): where triangle i's 64-B record sits ----
+    // ---- slots of the intersection stream (mipt::tri_slots, layout_order.cpp): where triangle i's 64-B record sits ----
     std::vector<uint32_t> slot_of_tri(desc->n_tris);
     uint32_t n_slots = 0;
     if (mipt::tri_slots(desc->nodes, desc->n_nodes, desc->n_tris, slot_of_tri.data(), &n_slots) != MIPT_OK)
@@ -74,7 +74,7 @@ int host_layout(const MiptSceneDesc *desc, uint8_t *geom_out, uint64_t geom_cap,
             }
         }
     });
-    // ---- order of the pair records in HBM (mipt::pair_order, bvh_build.cpp): the tree top breadth-first, below it every
+    // ---- order of the pair records in HBM (mipt::pair_order, layout_order.cpp): the tree top breadth-first, below it every
     // pair in one 128-B line with the child pair of its larger inner child.  Topology, visit order and results are untouched; only
     // `a` of the inner children is renumbered.
     std::vector<uint32_t> new_of(n_pairs);                                  // reference pair index -> record index in HBM
@@ -84,7 +84,7 @@ int host_layout(const MiptSceneDesc *desc, uint8_t *geom_out, uint64_t geom_cap,
         uint32_t n_records = 0;
         {
             const uint32_t cap = order.size() < (size_t)mipt::kMaxPairs ? (uint32_t)order.size() : mipt::kMaxPairs;
-            const int rc = mipt::pair_order(desc->nodes, desc->n_nodes, order.data(), cap, &n_records);   // bvh_build.cpp
+            const int rc = mipt::pair_order(desc->nodes, desc->n_nodes, order.data(), cap, &n_records);
             if (rc != MIPT_OK) return rc;
         }
         order.resize(n_records);

@@ -1,6 +1,6 @@
-// layout_hooks.cpp -- part of libmipt_diag.so (test infrastructure): re-exports the library-internal layout functions of
-// rust_ray_tracing_amd/csrc/bvh_build.cpp (mipt::pair_order / pair_order_top / tri_slots, hidden in libmipt.so) so that
-// tests/test_host_layout.py and tests/tools/layout_model.py can call them.  libmipt_diag.so links the same bvh_build.o as the product.
+// layout_hooks.cpp -- part of libmipt_diag.so (test infrastructure): C entry points to the host restatements of the device layout's two
+// orders (tests/cpp/layout_order.cpp: mipt::pair_order / tri_slots; pair_order_top is the product's constant) so that
+// tests/test_host_layout.py and tests/tools/layout_model.py can call them.
 #include "../../include/mipt_diag.h"
 #include "../../rust_ray_tracing_amd/csrc/mipt_internal.h"
 

@@ -1,6 +1,6 @@
 // ASan/UBSan build of the host-side C++ (BVH builder, OBJ/MTL loader, PNG / JPEG / TGA / BMP decoders) -- GPU sanitizers are unavailable on
 // the pool, so memory safety of everything that parses untrusted files is checked on the CPU build:
-//   g++ -fsanitize=address,undefined bvh_build.cpp obj_loader.cpp png_decode.cpp jpeg_decode.cpp tga_bmp_decode.cpp sanitize_host.cpp
+//   g++ -fsanitize=address,undefined bvh_build.cpp obj_loader.cpp png_decode.cpp jpeg_decode.cpp tga_bmp_decode.cpp layout_order.cpp sanitize_host.cpp
 // Feeds the loader valid files, truncated files and bit-flipped PNGs / JPEGs; builds BVHs over random soups.
 #include "mipt.h"
 
@@ -14,7 +14,7 @@
 
 static std::string g_err;
 void mipt_internal_set_error(const char *m) { g_err = m ? m : ""; }
-#include "../../rust_ray_tracing_amd/csrc/mipt_internal.h"   // mipt::pair_order / mipt::tri_slots (bvh_build.cpp)
+#include "../../rust_ray_tracing_amd/csrc/mipt_internal.h"   // mipt::pair_order / mipt::tri_slots (tests/cpp/layout_order.cpp)
 #include "../../rust_ray_tracing_amd/csrc/copy_crew.h"       // the copy threads of the staged scene upload (scene_device.hip)
 extern "C" void mipt_material_default(MiptMaterial *m) { memset(m, 0, sizeof *m); m->base_color = {0.8f, 0.8f, 0.8f}; m->base_color_tex_id = m->emission_tex_id = UINT32_MAX; }
 namespace mipt_png { bool decode(const std::string &, uint32_t *, uint32_t *, std::vector<uint8_t> *, std::string *); }

@@ -59,7 +59,8 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
                            os.path.join(src, "bvh_build.cpp"), os.path.join(src, "obj_loader.cpp"), os.path.join(src, "png_decode.cpp"),
-                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(src, "tga_bmp_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe, "-lpthread"])
+                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(src, "tga_bmp_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "layout_order.cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe, "-lpthread"])
     jpegs = []
     try:
         from PIL import Image
@@ -88,7 +89,8 @@ def test_host_code_under_asan_ubsan(built, tmp_path):
     exe_t = str(tmp_path / "sanitize_host_tsan")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
                            os.path.join(src, "bvh_build.cpp"), os.path.join(src, "obj_loader.cpp"), os.path.join(src, "png_decode.cpp"),
-                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(src, "tga_bmp_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe_t, "-lpthread"])
+                           os.path.join(src, "jpeg_decode.cpp"), os.path.join(src, "tga_bmp_decode.cpp"), os.path.join(ROOT, "tests", "cpp", "layout_order.cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"), "-o", exe_t, "-lpthread"])
     out = subprocess.run([exe_t, str(tmp_path), str(tmp_path / "tex.png")] + jpegs, capture_output=True, text=True,
                          env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert out.returncode == 0 and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
