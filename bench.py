@@ -513,8 +513,8 @@ def main():
                              "geometry_bytes": setup_info["geometry_bytes"],
                              "note": "one call (after the process's frame buffers exist, i.e. not the process's first device allocation): "
                                      "triangles host -> device once (staged through a pinned ring), BVH::build (bvh.rs:13-161) and the whole "
-                                     "device layout in HBM; identical tree, byte-identical layout to mipt_bvh_build + mipt_scene_create "
-                                     "(tests/test_gpu_scene_device.py, tests/test_gpu_fullsize.py); round 3: 0.44 s + 0.89 s"}
+                                     "device layout in HBM; tree identical to mipt_bvh_build's, layout byte-identical to the host restatement in "
+                                     "libmipt_diag.so (tests/test_gpu_scene_device.py, tests/test_gpu_fullsize.py); round 3: 0.44 s + 0.89 s"}
     # ---- N = 1: the in-library multi-GPU path (mipt_render_multi: RCCL communicator + gather / reduce behind the C ABI) ----
     if rank == 0 and world == 1 and not single and not args.no_render_multi:
         try:
