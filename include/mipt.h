@@ -170,7 +170,7 @@ enum MiptStatus {
  * records and splitting triangles into an intersection stream (40 B of payload -- v0, e1, e2 and the triangle's
  * reference index -- at a 64-byte stride, so a record never straddles a 128-byte line) and a 64-byte shading stream.  The tree is
  * validated on the host first (MIPT_ERR_BVH / _SCENE_LIMIT / _INVALID_ARG before any device call); triangles and nodes then cross PCIe
- * once and the layout is produced by GPU kernels (10 M triangles: 0.09 s).  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
+ * once and the layout is produced by GPU kernels (10 M triangles: 0.07 s).  Replaces State::new / StorageBuffers::new (gpu.rs:96-118, 329-401). */
 MIPT_API int mipt_scene_create(const MiptSceneDesc *desc, int device_id, MiptScene **out);
 MIPT_API void mipt_scene_destroy(MiptScene *scene);
 

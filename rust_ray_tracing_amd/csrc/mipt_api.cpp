@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -316,38 +318,83 @@ static int scene_create_many(const MiptSceneDesc *desc, const int *device_ids, i
     const double t_begin = now_ms();
 
     // ---- validate the BVH on the host, before anything touches the device (the layout kernels index with these fields) ----
-    std::vector<uint8_t> pair_seen(n_pairs, 0), tri_seen(desc->n_tris, 0);
-    for (uint32_t i = 0; i < desc->n_nodes; i++) {
-        const MiptNode &n = desc->nodes[i];
-        {   // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused).  (Axes with tiny
+    // On up to 16 threads, and with the verdict of a sequential scan over the nodes: the error reported is the one at the LOWEST node
+    // index (a node's own checks before its claims).  Every leaf claims its triangles and every inner node its child pair with an
+    // atomic min of the node index; a second pass finds the claims a node lost -- "belongs to more than one ... (node i is the
+    // second)" is then node i's error exactly when a lower node claimed the same thing, as in the sequential scan.
+    {
+        constexpr uint32_t kFree = 0xffffffffu;
+        struct Err { uint32_t node = kFree; int kind = 0; uint32_t a = 0; };     // kind 1 bound, 2 leaf range, 3 child index, 4 shared pair, 5 shared triangle
+        std::unique_ptr<uint32_t[]> pair_owner(new uint32_t[n_pairs ? n_pairs : 1]), tri_owner(new uint32_t[desc->n_tris]);
+        parallel_for(n_pairs, [&](size_t b, size_t e) { for (size_t k = b; k < e; k++) pair_owner[k] = kFree; });
+        parallel_for(desc->n_tris, [&](size_t b, size_t e) { for (size_t t = b; t < e; t++) tri_owner[t] = kFree; });
+        std::mutex mu;
+        Err first;
+        auto report = [&](uint32_t node, int kind, uint32_t a) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (node < first.node) { first.node = node; first.kind = kind; first.a = a; }
+        };
+        auto claim = [](uint32_t *p, uint32_t i) {
+            uint32_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+            while (i < cur && !__atomic_compare_exchange_n(p, &cur, i, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        };
+        auto own_error = [&](uint32_t i) -> int {                          // the checks that need nothing but node i
+            const MiptNode &n = desc->nodes[i];
+            // the kernel's exact-division fast path assumes finite bounds of magnitude <= 2^40 (beyond: refused).  (Axes with tiny
             // non-zero plane coordinates and the largest leaf are found by the device's own pass over the nodes, scene_device.hip.)
             const float lim = 1.0995116e12f;
             const float *b = &n.bounds_min.x, *c = &n.bounds_max.x;
-            for (int k = 0; k < 3; k++)
-                if (!(fabsf(b[k]) <= lim) || !(fabsf(c[k]) <= lim))
-                    return fail(MIPT_ERR_SCENE_LIMIT, "node %u has a non-finite bound or one beyond 2^40", i);
-        }
-        if (n.num_tris > 0) {
-            if ((uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris)
-                return fail(MIPT_ERR_BVH, "leaf node %u covers triangles [%u, %u+%u) beyond n_tris=%u", i, n.first_tri_or_child, n.first_tri_or_child, n.num_tris, desc->n_tris);
-            // leaves partition the triangle array (bvh.rs:99-115 splits a node's range in place); the device stream re-packs
-            // leaf by leaf, so a triangle in two leaves cannot be represented
-            for (uint32_t t = n.first_tri_or_child; t < n.first_tri_or_child + n.num_tris; t++) {
-                if (tri_seen[t]) return fail(MIPT_ERR_BVH, "triangle %u belongs to more than one leaf (node %u is the second)", t, i);
-                tri_seen[t] = 1;
+            for (int k = 0; k < 3; k++) if (!(fabsf(b[k]) <= lim) || !(fabsf(c[k]) <= lim)) return 1;
+            if (n.num_tris > 0) return (uint64_t)n.first_tri_or_child + n.num_tris > desc->n_tris ? 2 : 0;
+            const uint32_t c2 = n.first_tri_or_child;
+            return ((c2 & 1u) == 0u || (uint64_t)c2 + 1u >= desc->n_nodes || c2 <= i) ? 3 : 0;
+        };
+        parallel_for(desc->n_nodes, [&](size_t nb, size_t ne) {
+            for (size_t ii = nb; ii < ne; ii++) {
+                const uint32_t i = (uint32_t)ii;
+                const int k = own_error(i);
+                if (k) { report(i, k, 0); return; }                       // the rest of this range lies above an error: irrelevant
+                const MiptNode &n = desc->nodes[i];
+                // leaves partition the triangle array (bvh.rs:99-115 splits a node's range in place); the device stream re-packs leaf by
+                // leaf, so a triangle in two leaves cannot be represented.  A tree, not a DAG: BVH::split_node pushes every child pair once
+                // (bvh.rs:115-132).
+                if (n.num_tris > 0) for (uint32_t t = n.first_tri_or_child; t < n.first_tri_or_child + n.num_tris; t++) claim(&tri_owner[t], i);
+                else claim(&pair_owner[(n.first_tri_or_child - 1u) / 2u], i);
             }
-        } else {
-            const uint32_t c = n.first_tri_or_child;
-            if ((c & 1u) == 0u || (uint64_t)c + 1u >= desc->n_nodes || c <= i)
-                return fail(MIPT_ERR_BVH, "inner node %u has child index %u (must be odd, > parent, and c+1 < n_nodes=%u)", i, c, desc->n_nodes);
-            // a tree, not a DAG: BVH::split_node pushes every child pair once (bvh.rs:115-132).  Two inner nodes sharing a pair
-            // would make the breadth-first record order below grow exponentially with depth.
-            if (pair_seen[(c - 1u) / 2u]) return fail(MIPT_ERR_BVH, "child pair at node %u is referenced by more than one inner node (node %u is the second)", c, i);
-            pair_seen[(c - 1u) / 2u] = 1;
+        });
+        const uint32_t upto = first.node == kFree ? desc->n_nodes : first.node;     // nodes above an error no longer matter
+        parallel_for(upto, [&](size_t nb, size_t ne) {
+            for (size_t ii = nb; ii < ne; ii++) {
+                const uint32_t i = (uint32_t)ii;
+                const MiptNode &n = desc->nodes[i];
+                if (n.num_tris > 0) {
+                    for (uint32_t t = n.first_tri_or_child; t < n.first_tri_or_child + n.num_tris; t++)
+                        if (tri_owner[t] != i) { report(i, 5, t); return; }
+                } else if (pair_owner[(n.first_tri_or_child - 1u) / 2u] != i) { report(i, 4, n.first_tri_or_child); return; }
+            }
+        });
+        if (first.node != kFree) {
+            const uint32_t i = first.node;
+            const MiptNode &n = desc->nodes[i];
+            switch (first.kind) {
+            case 1: return fail(MIPT_ERR_SCENE_LIMIT, "node %u has a non-finite bound or one beyond 2^40", i);
+            case 2: return fail(MIPT_ERR_BVH, "leaf node %u covers triangles [%u, %u+%u) beyond n_tris=%u", i, n.first_tri_or_child, n.first_tri_or_child, n.num_tris, desc->n_tris);
+            case 3: return fail(MIPT_ERR_BVH, "inner node %u has child index %u (must be odd, > parent, and c+1 < n_nodes=%u)", i, n.first_tri_or_child, desc->n_nodes);
+            case 4: return fail(MIPT_ERR_BVH, "child pair at node %u is referenced by more than one inner node (node %u is the second)", first.a, i);
+            default: return fail(MIPT_ERR_BVH, "triangle %u belongs to more than one leaf (node %u is the second)", first.a, i);
+            }
         }
+        std::atomic<uint32_t> orphan{kFree};
+        parallel_for(n_pairs, [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; k++) {
+                if (pair_owner[k] != kFree) continue;
+                uint32_t cur = orphan.load();
+                while ((uint32_t)k < cur && !orphan.compare_exchange_weak(cur, (uint32_t)k)) {}
+                return;
+            }
+        });
+        if (orphan.load() != kFree) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * orphan.load() + 1, 2 * orphan.load() + 2);
     }
-    for (uint32_t k = 0; k < n_pairs; k++)
-        if (!pair_seen[k]) return fail(MIPT_ERR_BVH, "nodes %u and %u are not the children of any inner node", 2 * k + 1, 2 * k + 2);
     // the reference indexes `materials[material_id]` and would panic; the lowest offender is reported, as a sequential scan would
     {
         std::atomic<uint32_t> bad_tri{UINT32_MAX};
