@@ -120,6 +120,42 @@ def test_random_soups(rrt, orc, n, seed, degenerate):
     _check_scene(rrt, orc, tris, [rrt.material_default()], [], ((12.0, 0.5, 0.3), 0.0, 0.0), w=64, h=36, spp=1, depth=4)
 
 
+def test_callers_tree_with_unreferenced_triangles(rrt, orc):
+    """mipt_scene_create takes any tree that passes its checks, not only BVH::build's: leaves that shrank (triangles no leaf refers to:
+    they get slots after the referenced ones and are never hit), a root that is a leaf.  Device layout == host restatement, frame == oracle."""
+    from rust_ray_tracing_amd import NODE, synth
+    from rust_ray_tracing_amd import _lib as L
+    tris, mats, texs, cam = synth.make_scene("atrium", n_target=20000, tex_size=16)
+    base = rrt.Scene.from_arrays(tris, mats, texs)
+    nodes = base.bvh_nodes.copy()
+    two = np.flatnonzero(nodes["num_tris"] == 2)
+    assert len(two) > 30
+    nodes["num_tris"][two[::3]] = 1                                # every third 2-triangle leaf drops its second triangle
+    nodes["first_tri_or_child"][two[1::3]] += 1                     # ... or its first
+    nodes["num_tris"][two[1::3]] = 1
+    cases = [(base.tris, nodes)]
+    leaf = np.zeros(1, dtype=NODE)                                  # BVH::build's answer for a scene it refuses to split (bvh.rs:94)
+    leaf["bounds_min"], leaf["bounds_max"] = base.bvh_nodes["bounds_min"][0], base.bvh_nodes["bounds_max"][0]
+    leaf["num_tris"] = 5
+    cases.append((base.tris[:9].copy(), leaf))
+    for t, n in cases:
+        sc = rrt.Scene.from_arrays(t, mats, texs, build_bvh=False)
+        sc.bvh_nodes = n
+        h = sc.upload(0)
+        g0, a0, i0 = sc.host_layout()
+        g1, a1, h1 = _layout(rrt, h)
+        assert np.array_equal(g1, g0) and np.array_equal(a1, a0) and h1 == sc.host_layout_fingerprint()[:2]
+        info = sc.info()
+        assert info["built_on_device"] == 0 and info["n_pair_records"] == i0["n_pair_records"] and info["max_leaf"] == i0["max_leaf"]
+        sc.set_camera(rrt.Camera(position=cam[0], pitch=cam[1], yaw=cam[2]))
+        r = rrt.Renderer.new(rrt.RendererOptions(samples=2, max_ray_depth=6, output_image_dimensions=(64, 40), output_image_path="/dev/null"))
+        f1, p1, s1 = r.render_buffers(sc, flags=L.FLAG_COUNT)
+        of, op_, os_ = orc.render(sc.tris, sc.bvh_nodes, sc.materials_array(), sc.textures, sc.camera.uniform, 64, 40, 2, 6)
+        assert np.array_equal(f1.view(np.uint32), of.view(np.uint32)) and np.array_equal(p1, op_)
+        assert s1["rays"] == os_["rays"] and s1["tri_tests"] == os_["tri_tests"]
+        sc.release()
+
+
 def test_errors_are_status_codes(rrt):
     from rust_ray_tracing_amd import _lib as L
     lib = rrt.load()
