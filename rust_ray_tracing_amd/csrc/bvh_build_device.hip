@@ -1352,7 +1352,7 @@ int fail(int code, const char *what, hipError_t e) {
 void mipt::bvh_builder_resolve_kernels() {
     const void *k[] = {(const void *)make_proxies, (const void *)init_root, (const void *)level_mark, (const void *)big_setup, (const void *)big_bin, (const void *)big_choose,
                        (const void *)big_count2, (const void *)big_scan, (const void *)big_fill, (const void *)big_scatter, (const void *)big_finish,
-                       (const void *)build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>, (const void *)build_level_wave<128u, kWaveM, 8, 4>,
+                       (const void *)build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>, (const void *)build_level_wave<128u, kWaveM, 8, 3>,
                        (const void *)build_level_wave<kWaveS, 128u, 8, 6>, (const void *)build_level_wave<32u, kWaveS, 8, 8>, (const void *)build_level_group<32, 16u, 32u>,
                        (const void *)build_level_group<16, kTiny, 16u>, (const void *)build_level_tiny, (const void *)build_subtree_tiny, (const void *)sizes_level,
                        (const void *)sizes_run, (const void *)bases_level, (const void *)bases_run, (const void *)extract_order};
@@ -1479,7 +1479,7 @@ int mipt::bvh_build_resident(const MiptTriangle *d_tris, uint32_t n_tris, int de
         const uint32_t ng16 = hc.cnt[row][CLS_G16].v, ng32 = hc.cnt[row][CLS_G32].v, nwa = hc.cnt[row][CLS_WAVE_A].v;
         if (nwl) hipLaunchKernelGGL((build_level_wave<kWaveM, (kWaveMax > kWaveM ? kWaveMax : 2u * kWaveM), kWaveBigNodes, 2>), dim3((nwl + (uint32_t)kWaveBigNodes - 1u) / (uint32_t)kWaveBigNodes), dim3(64 * kWaveBigNodes), 0, sw3,
                                     d_bn, ls.l[parity][CLS_WAVE_L], nwl, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
-        if (nwm) hipLaunchKernelGGL((build_level_wave<128u, kWaveM, 8, 4>), dim3((nwm + 7u) / 8u), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE_M], nwm, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
+        if (nwm) hipLaunchKernelGGL((build_level_wave<128u, kWaveM, 8, 3>), dim3((nwm + 7u) / 8u), dim3(512), 0, sw, d_bn, ls.l[parity][CLS_WAVE_M], nwm, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
         if (nwa) hipLaunchKernelGGL((build_level_wave<kWaveS, 128u, 8, 6>), dim3((nwa + 7u) / 8u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE_A], nwa, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
         if (nws) hipLaunchKernelGGL((build_level_wave<32u, kWaveS, 8, 8>), dim3((nws + 7u) / 8u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_WAVE], nws, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
         if (ng32) hipLaunchKernelGGL((build_level_group<32, 16u, 32u>), dim3((ng32 + 15u) / 16u), dim3(512), 0, sw2, d_bn, ls.l[parity][CLS_G32], ng32, d_px[cur], d_px[cur ^ 1], d_ctrl, ls, next);
