@@ -453,11 +453,12 @@ __device__ __forceinline__ WaveSplit wave_node(const BNode &nd, const Proxy *__r
 // ---- 5. children: the workgroup's waves hand their splits to wave 0, which allocates the child nodes and queues them with
 // ONE set of atomics per workgroup (a per-node atomic on the shared counters serialises in L2: ~6 ns each, which was the whole
 // cost of the deep levels) ----
-// Three instantiations, each with its own class list and stream, take the nodes with LO < n <= HI triangles: <= 64 (one proxy per lane: a third of the registers, so 8 waves per SIMD -- a node is a
-// chain of dependent memory round trips, and most wave-class nodes are this small), <= 512 (8 proxies per lane, 4 waves per SIMD)
-// and <= kWaveMax (kWaveMax / 64 proxies per lane, 2 waves per SIMD, fewer nodes per workgroup for the LDS position lists).  Reading
-// a node once into registers and writing it once is what makes this kernel ~10x faster per triangle than build_level's eight
-// passes over global memory -- hence the wide range.
+// Four instantiations, each with its own class list, take the nodes with LO < n <= HI triangles: 33..64 (one proxy per lane: a third of
+// the registers, so 8 waves per SIMD -- a node is a chain of dependent memory round trips, and most wave-class nodes are this small),
+// 65..128 (2 per lane, 6 waves), 129..512 (8 per lane, 3 waves: at 4 the kernel spilled 68 B per lane for the same time) and
+// 513..kWaveMax (kWaveMax / 64 proxies per lane, 2 waves per SIMD, fewer nodes per workgroup for the LDS position lists).  Reading a
+// node once into registers and writing it once is what made this kernel ~10x faster per triangle than the one-workgroup-per-node
+// kernel of round 3 with its eight passes over global memory -- hence the wide range.
 template <uint32_t LO, uint32_t HI, int NODES, int MINW>
 __global__ __launch_bounds__(64 * NODES, MINW) void build_level_wave(BNode *bn, const uint32_t *__restrict__ list, uint32_t count,
                                                                       const Proxy *__restrict__ pin, Proxy *__restrict__ pout, Ctrl *ctrl,
